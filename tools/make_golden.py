@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference implementation.
+
+Runs ONLY in the development container (the reference lives read-only at
+/root/reference and never travels to the GPU box).  This is the one file in the
+repo that imports the reference; it copies none of its source.  Each fixture
+holds inputs and the reference's outputs for one hot-path case:
+
+  params.*        state_dict before the step          x, u, eps     inputs
+  g v l f z       forward tensors                     lpx lqc lp    per-row log-densities
+  loss            the value to MINIMISE (family A's return; minus family B's)
+  grad.*          d loss / d param from loss.backward()
+  adam{k}.*       params / exp_avg / exp_avg_sq after k optimiser steps
+                  (steps 1-3 at lr 1e-2, step 4 after an lr drop to 1e-3)
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from models.nets import iVAE, VAE, cleanIVAE, cleanVAE, Normal, log_normal  # noqa: E402
+from metrics.mcc import mean_corr_coef_np  # noqa: E402
+
+
+def onehot_u(B, M, gen):
+    u = torch.zeros(B, M)
+    u[torch.arange(B), torch.randint(0, M, (B,), generator=gen)] = 1
+    return u
+
+
+def make_case(name, family, dims, B, coef=None, anneal_it=None, max_iter=1000, N=40000, seed=0,
+              act="lrelu", H=50, n_layers=3, slope=.1, dense_u=False, store_steps=True):
+    torch.manual_seed(seed)
+    d_lat, d_data, M = dims
+    if family == "iVAE":
+        model = iVAE(d_lat, d_data, M, n_layers=n_layers, hidden_dim=H, activation=act, slope=slope,
+                     anneal=anneal_it is not None)
+    elif family == "VAE":
+        model = VAE(d_lat, d_data, n_layers=n_layers, hidden_dim=H, activation=act, slope=slope)
+    elif family == "cleanIVAE":
+        model = cleanIVAE(d_data, d_lat, M, n_layers=n_layers, activation=act, hidden_dim=H, slope=slope)
+    elif family == "cleanVAE":
+        model = cleanVAE(d_data, d_lat, n_layers=n_layers, activation=act, hidden_dim=H, slope=slope)
+    else:
+        raise ValueError(family)
+    has_u = family in ("iVAE", "cleanIVAE")
+    clean = family.startswith("clean")
+    gen = torch.Generator().manual_seed(1000 + seed)
+    out = {}
+    meta = dict(name=name, family=family, latent_dim=d_lat, data_dim=d_data, aux_dim=M if has_u else 0,
+                hidden_dim=H, n_layers=n_layers, activation=act, slope=slope, batch=B, N=N,
+                decoder_var=float(model.decoder_var.item()), torch=torch.__version__)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+
+    def one_step(k):
+        x = torch.randn(B, d_data, generator=gen) * 1.5
+        if has_u:
+            u = torch.rand(B, M, generator=gen) if dense_u else onehot_u(B, M, gen)
+        else:
+            u = torch.zeros(B, 1)
+        if anneal_it is not None:
+            model.anneal(N, max_iter, anneal_it + k)
+        opt.zero_grad()
+        st = torch.get_rng_state()
+        if clean:
+            a, b, c, d = coef
+            loss, z = model.elbo(x, u, N, a=a, b=b, c=c, d=d)
+            co = dict(a=a, b=b, c=c, d=d, N=N, pairwise=True)
+        else:
+            pair = bool(getattr(model, "anneal_params", False))
+            if pair:
+                a, b, c, d, Nn = model._training_hyperparams
+                co = dict(a=a, b=b, c=c, d=d, N=Nn, pairwise=True)
+            else:
+                co = dict(a=1., b=1., c=1., d=1., N=N, pairwise=False)
+            elbo, z = model.elbo(x, u) if has_u else model.elbo(x)
+            loss = elbo.mul(-1)
+        # recover eps exactly: the reference draws torch.randn(B, d) (nets.py:147,302)
+        torch.set_rng_state(st)
+        eps = torch.randn(B, d_lat)
+        torch.set_rng_state(st)
+        with torch.no_grad():
+            fw = model(x, u) if has_u else model(x)
+        if clean:
+            f, g, v, z2 = fw[0], fw[1], fw[2], fw[3]
+            l = fw[4] if has_u else torch.ones_like(g)
+        else:
+            (f, _), (g, v), z2, (_, l) = fw
+            if not has_u:
+                l = torch.ones_like(g)
+        assert torch.equal(z2, z.detach()), "rng replay failed"
+        assert torch.equal(z2, eps.mul(v.sqrt()).add(g)), "eps recovery failed"
+        with torch.no_grad():
+            dvar = model.decoder_var
+            if clean:
+                lpx = log_normal(x, f, dvar).sum(-1)
+                lqc = log_normal(z2, g, v).sum(-1)
+                lp = log_normal(z2, None, l).sum(-1)
+            else:
+                nd = Normal()
+                lpx = nd.log_pdf(x, f, dvar)
+                lqc = nd.log_pdf(z2, g, v)
+                lp = nd.log_pdf(z2, torch.zeros(1), l)
+        rec = dict(x=x, u=u, eps=eps, g=g, v=v, l=l.expand_as(g), f=f, z=z2, lpx=lpx, lqc=lqc, lp=lp,
+                   loss=loss.detach())
+        return loss, rec, co
+
+    # step 0 record (pre-update params, grads)
+    for kname, val in model.state_dict().items():
+        out["params." + kname] = val.detach().clone().numpy()
+    loss, rec, co = one_step(0)
+    loss.backward()
+    for k_, v_ in rec.items():
+        out[k_] = v_.numpy()
+    for kname, p in model.named_parameters():
+        out["grad." + kname] = p.grad.detach().clone().numpy()
+    meta["coef"] = co
+    opt.step()
+    step_meta = [co]
+
+    def dump_adam(k):
+        sd = opt.state_dict()["state"]
+        for i, (kname, p) in enumerate(model.named_parameters()):
+            out[f"adam{k}.p.{kname}"] = p.detach().clone().numpy()
+            out[f"adam{k}.m.{kname}"] = sd[i]["exp_avg"].clone().numpy()
+            out[f"adam{k}.v.{kname}"] = sd[i]["exp_avg_sq"].clone().numpy()
+
+    if store_steps:
+        dump_adam(1)
+    for k in (1, 2, 3):
+        if k == 3:
+            for gparam in opt.param_groups:
+                gparam["lr"] = 1e-3
+        loss, rec, co = one_step(k)
+        loss.backward()
+        opt.step()
+        step_meta.append(co)
+        for k_ in ("x", "u", "eps", "loss"):
+            out[f"step{k}.{k_}"] = rec[k_].numpy()
+        if store_steps or k == 3:
+            dump_adam(k + 1)
+    meta["steps"] = step_meta
+    meta["lrs"] = [1e-2, 1e-2, 1e-2, 1e-3]
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name:28s} loss={float(out['loss']):.6f} params={sum(v.size for k, v in out.items() if k.startswith('params.'))}")
+
+
+def make_mcc():
+    rng = np.random.RandomState(7)
+    out = {}
+    cases = [(64, 10), (64, 5), (256, 20), (5000, 10), (37, 3)]
+    for i, (n, d) in enumerate(cases):
+        s = rng.randn(n, d).astype(np.float32)
+        mix = rng.randn(d, d).astype(np.float32)
+        y = (np.tanh(s @ mix) + 0.3 * rng.randn(n, d)).astype(np.float32)
+        out[f"x{i}"], out[f"y{i}"] = s, y
+        out[f"cc{i}"] = np.corrcoef(s, y, rowvar=False)[:d, d:]
+        out[f"mcc{i}"] = np.array(mean_corr_coef_np(s, y))
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT, "mcc.npz"), **out)
+    print("mcc fixtures", [float(out[f"mcc{i}"]) for i in range(len(cases))])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # family B (models/nets.py:391-486, 548-599)
+    make_case("ivae_plain_tiny", "iVAE", (3, 3, 4), B=5, H=8)
+    make_case("ivae_plain_cfg2", "iVAE", (10, 10, 40), B=64, H=50)
+    make_case("ivae_plain_b70", "iVAE", (4, 6, 7), B=70, H=20, dense_u=True)
+    make_case("ivae_plain_l2_sigmoid", "iVAE", (3, 5, 4), B=9, H=12, n_layers=2, act="sigmoid")
+    make_case("ivae_plain_l4_none", "iVAE", (3, 4, 5), B=11, H=7, n_layers=4, act="none")
+    make_case("ivae_plain_l1", "iVAE", (3, 3, 4), B=6, H=5, n_layers=1)
+    make_case("ivae_anneal_tiny", "iVAE", (3, 3, 4), B=5, H=8, anneal_it=300)
+    make_case("ivae_anneal_cfg2", "iVAE", (10, 10, 40), B=64, H=50, anneal_it=1)
+    make_case("ivae_anneal_switch", "iVAE", (3, 3, 4), B=8, H=8, anneal_it=623)  # crosses thr=625 -> plain
+    make_case("vae_plain_tiny", "VAE", (3, 4, 0), B=7, H=8)
+    make_case("vae_plain_cfg2", "VAE", (10, 10, 0), B=64, H=50)
+    make_case("ivae_plain_cfg4s", "iVAE", (20, 20, 200), B=96, H=50, N=1000000, store_steps=False)
+    # family A (models/nets.py:124-243), coefficients from configs/{ivae,bvae,btcvae,vae}.yaml:24-27
+    make_case("cleanivae_tiny", "cleanIVAE", (3, 3, 4), B=5, H=8, act="xtanh", coef=(100, 1, 0, 10))
+    make_case("cleanivae_cfg1", "cleanIVAE", (5, 5, 40), B=64, H=100, act="xtanh", coef=(100, 1, 0, 10),
+              store_steps=False)
+    make_case("cleanivae_lrelu_b70", "cleanIVAE", (4, 6, 7), B=70, H=20, act="lrelu", coef=(2, 3, 1.5, 0.5))
+    make_case("cleanvae_tiny", "cleanVAE", (3, 4, 0), B=6, H=8, act="xtanh", coef=(500, 5, 5, 5))
+    make_case("cleanvae_bvae", "cleanVAE", (5, 5, 0), B=64, H=100, act="xtanh", coef=(500, 5, 5, 5),
+              store_steps=False)
+    make_case("cleanvae_btcvae", "cleanVAE", (5, 5, 0), B=64, H=100, act="xtanh", coef=(1000, 1, 15, 1),
+              store_steps=False)
+    make_case("cleanvae_btcvae_b200", "cleanVAE", (5, 5, 0), B=200, H=100, act="xtanh", coef=(1000, 1, 15, 1),
+              store_steps=False)
+    make_mcc()
+
+
+if __name__ == "__main__":
+    main()
