@@ -1,0 +1,151 @@
+/*
+ * ivae_amd.h -- C ABI of libivae_amd.so: the MI355X (gfx950) implementation of the
+ * iVAE training hot path (ELBO forward/backward + Adam + MCC correlation).
+ *
+ * The reference (ilkhem/iVAE) is pure Python with no FFI; the interface it would bind
+ * is the set of torch calls its nn.Module methods make.  Every entry point below names
+ * the reference lines (relative to the reference root) it replaces.
+ *
+ * Conventions
+ *   - all tensors are fp32, row-major (batch, feature), resident in device memory and
+ *     owned by the caller; the library never allocates or frees device memory;
+ *   - nn.Linear.weight is (out, in); a model's parameters travel as ONE flat fp32 arena
+ *     in `parameters()` order: for each MLP in [logl (iVAE only), f, g, logv], for each
+ *     layer: weight (out*in) then bias (out)           (models/nets.py:422-430, 99-106);
+ *   - n_models > 1 = batched-model packing: every per-model array (params, grads, x, u,
+ *     eps, z, loss, workspace) is the single-model array repeated with a fixed stride;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no internal sync;
+ *   - return value 0 = ok, negative IVAE_E_* otherwise; never aborts, never prints.
+ */
+#ifndef IVAE_AMD_H
+#define IVAE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { IVAE_ACT_NONE = 0, IVAE_ACT_LRELU = 1, IVAE_ACT_XTANH = 2, IVAE_ACT_SIGMOID = 3 };
+
+enum {
+    IVAE_OK = 0,
+    IVAE_E_BADDIMS = -1,      /* non-positive / unsupported dimension */
+    IVAE_E_BADACT = -2,       /* unknown activation id */
+    IVAE_E_NULLPTR = -3,      /* a required pointer is NULL */
+    IVAE_E_TOOLARGE = -4,     /* shape exceeds what the kernels' LDS tiling supports */
+    IVAE_E_HIP = -5,          /* a HIP call failed; see ivae_last_hip_error() */
+    IVAE_E_WORKSPACE = -6     /* workspace smaller than ivae_workspace_bytes() */
+};
+
+/* Shape of one model and of one call.  Mirrors the constructor arguments at
+ * models/nets.py:125,190,392-393,550-551. */
+typedef struct IvaeDims {
+    int32_t batch;        /* rows in this call (the local shard under data parallelism) */
+    int32_t data_dim;
+    int32_t latent_dim;
+    int32_t aux_dim;      /* 0 selects the VAE family: no prior MLP, prior variance 1 */
+    int32_t hidden_dim;
+    int32_t n_layers;     /* >= 1; n_layers-1 hidden layers of width hidden_dim */
+    int32_t activation;   /* IVAE_ACT_* (models/nets.py:86-97) */
+    float   slope;        /* lrelu negative slope / xtanh linear term */
+    int32_t n_models;     /* >= 1 */
+} IvaeDims;
+
+/* Loss definition.  loss = -(1/Bg) * sum_i [ a*lpx - b*(lqc-lq) - c*(lq-lqi) - d*(lqi-lp) ]
+ * (models/nets.py:184,242,471) when pairwise != 0, else -(1/Bg) * sum_i [a*lpx - b*lqc + d*lp]
+ * (models/nets.py:475,599 with a=b=d=1).  Bg = global_batch. */
+typedef struct IvaeCoef {
+    float   a, b, c, d;
+    float   dataset_size;   /* N in log(M*N), models/nets.py:181,468 */
+    float   decoder_var;    /* .01 (nets.py:425,574) or .1 (nets.py:140,204) */
+    int32_t pairwise;       /* 1: include the BxBxd total-correlation terms */
+    int32_t global_batch;   /* batch of the whole step; == dims.batch unless data parallel */
+} IvaeCoef;
+
+/* Float offsets (per model) of the row tensors inside the workspace, for callers that
+ * exchange them between ranks (data-parallel pairwise term) or read diagnostics. */
+typedef struct IvaeWsLayout {
+    int64_t per_model;      /* floats per model */
+    int64_t g, v, l, z, f;  /* (batch, latent|data) forward tensors, nets.py:450-455 */
+    int64_t lpx, lqc, lp, lq, lqi;   /* (batch,) per-row log-densities, nets.py:459-469 */
+    int64_t rz, cg, cv;     /* (batch, latent) pairwise gradient terms */
+    int64_t lse_s, lse_k;   /* (batch,), (batch, latent) log-sum-exp statistics */
+} IvaeWsLayout;
+
+/* ---- sizes -------------------------------------------------------------------------- */
+
+/* Number of fp32 parameters of one model (sum over nn.Linear layers). */
+int ivae_param_count(const IvaeDims* dims, int64_t* out);
+
+/* Bytes of caller-provided scratch the calls below need for `dims` (all models). */
+int ivae_workspace_bytes(const IvaeDims* dims, size_t* out);
+
+int ivae_workspace_layout(const IvaeDims* dims, IvaeWsLayout* out);
+
+/* ---- ELBO forward + backward ---------------------------------------------------------
+ * Replaces  model.elbo(x,u[,N,a,b,c,d]) -> loss.backward()
+ *   runners/ivae.py:76,82   models/wrappers.py:68-69,149-150
+ *   models/nets.py:172-185 (cleanIVAE), 230-243 (cleanVAE), 457-475 (iVAE), 593-599 (VAE)
+ * Inputs : params (n_models, P); x (n_models, batch, data_dim); u (n_models, batch, aux_dim)
+ *          or NULL when aux_dim == 0; eps (n_models, batch, latent_dim) standard-normal draws
+ *          (the torch.randn of nets.py:147,302).
+ * Outputs: z_out (n_models, batch, latent_dim); loss_out (n_models,) = the quantity to
+ *          minimise restricted to these rows (sums to the full loss over DP shards);
+ *          grads (n_models, P) = d loss / d params, same layout as params.
+ * Phases may also be called one by one (data-parallel pairwise term):
+ *   ivae_forward -> [ivae_pairwise] -> ivae_backward. */
+int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* params,
+                      const float* x, const float* u, const float* eps,
+                      float* z_out, float* loss_out, float* grads,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Forward only: models/nets.py:450-455, 587-591, 165-170, 224-228 plus the three per-row
+ * log-densities (nets.py:459-461).  Fills the workspace row tensors and z_out. */
+int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params,
+                 const float* x, const float* u, const float* eps, float* z_out,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* Pairwise log q(z_i | x_j) statistics and their gradient terms, never materialising the
+ * (B,B,d) tensor of models/nets.py:180-182, 466-469.  Rows i: z (n_rows, d) of this shard.
+ * Columns j: g_cols, v_cols (n_cols, d) of the GLOBAL batch.  Writes lq, lqi, rz (n_rows,*)
+ * and cg, cv (n_cols, d) (column sums over this shard's rows).  Single model only. */
+int ivae_pairwise(int32_t n_rows, int32_t n_cols, int32_t latent_dim, const IvaeCoef* coef,
+                  const float* z, const float* g_cols, const float* v_cols,
+                  float* lq, float* lqi, float* lse_s, float* lse_k,
+                  float* rz, float* cg, float* cv, void* stream);
+
+/* Backward of everything ivae_forward (+ ivae_pairwise) computed; autograd at
+ * runners/ivae.py:82, models/wrappers.py:69. */
+int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* params,
+                  const float* x, const float* u, const float* eps,
+                  float* loss_out, float* grads,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- Adam ---------------------------------------------------------------------------
+ * Replaces optimizer.step() of torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8)
+ *   runners/ivae.py:38,91   models/wrappers.py:44,70,127,151
+ * over a flat arena of n floats.  `step` is the 1-based step count of THIS update.
+ * lr is read per call (ReduceLROnPlateau mutates it, runners/ivae.py:39,113-114). */
+int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float* grads,
+                   int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+                   void* stream);
+
+/* ---- MCC correlation ------------------------------------------------------------------
+ * Replaces np.corrcoef(x, y, rowvar=False)[:d, d:] of metrics/mcc.py:328 (float64
+ * arithmetic on fp32 inputs).  x, y: (n, d) fp32; cc_out: (d, d) float64 on device.
+ * workspace: at least ivae_corr_workspace_bytes(n, d) bytes.  The Hungarian assignment
+ * (metrics/mcc.py:334) stays on the host. */
+int ivae_corr_workspace_bytes(int64_t n, int32_t d, size_t* out);
+int ivae_corr(const float* x, const float* y, int64_t n, int32_t d, double* cc_out,
+              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- diagnostics ---------------------------------------------------------------------- */
+const char* ivae_last_hip_error(void);   /* text of the last failing HIP call (thread-local) */
+const char* ivae_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVAE_AMD_H */

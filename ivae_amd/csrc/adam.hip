@@ -1,0 +1,36 @@
+// Fused Adam update over a flat parameter arena (one launch for all tensors / models).
+//
+// Arithmetic follows torch.optim.Adam's single-tensor CPU path (torch 2.10
+// optim/adam.py:457-547), the optimiser the reference constructs at runners/ivae.py:38 and
+// models/wrappers.py:44,127:   m.lerp_(g, 1-b1);  v.mul_(b2).addcmul_(g, g, 1-b2);
+//   denom = sqrt(v)/sqrt(1-b2^t) + eps;  p.addcdiv_(m, denom, -lr/(1-b1^t)).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "kernels.h"
+
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                              const float* __restrict__ g, int64_t n, float w1, float b2, float w2,
+                                              float neg_step, float bc2_sqrt, float eps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = m[i] + w1 * (gi - m[i]);
+        const float vi = v[i] * b2 + (w2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] + (neg_step * mi) / denom;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2,
+                       float eps, int64_t step, hipStream_t st) {
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    const float neg_step = (float)(-(double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, p, m, v, g, n, (float)(1.0 - (double)b1), b2,
+                       (float)(1.0 - (double)b2), neg_step, bc2_sqrt, eps);
+    return hipGetLastError();
+}

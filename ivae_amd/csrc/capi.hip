@@ -1,0 +1,137 @@
+// extern "C" surface of libivae_amd.so (declared in include/ivae_amd.h).
+// Validates shapes on the host before any launch, never allocates device memory, never
+// synchronises, never throws: every failure is an IVAE_E_* return code.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "kernels.h"
+
+static thread_local char g_err[256] = "";
+
+static int hip_fail(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return IVAE_E_HIP;
+}
+
+extern "C" {
+
+const char* ivae_last_hip_error(void) { return g_err; }
+const char* ivae_version(void) { return "ivae_amd 0.1 (gfx950)"; }
+
+int ivae_param_count(const IvaeDims* dims, int64_t* out) {
+    if (!out) return IVAE_E_NULLPTR;
+    Layout L;
+    int rc = ivae_make_layout(dims, &L);
+    if (rc) return rc;
+    *out = L.n_params;
+    return IVAE_OK;
+}
+
+int ivae_workspace_bytes(const IvaeDims* dims, size_t* out) {
+    if (!out) return IVAE_E_NULLPTR;
+    Layout L;
+    int rc = ivae_make_layout(dims, &L);
+    if (rc) return rc;
+    *out = (size_t)L.ws.per_model * L.n_models * sizeof(float);
+    return IVAE_OK;
+}
+
+int ivae_workspace_layout(const IvaeDims* dims, IvaeWsLayout* out) {
+    if (!out) return IVAE_E_NULLPTR;
+    Layout L;
+    int rc = ivae_make_layout(dims, &L);
+    if (rc) return rc;
+    *out = L.ws;
+    return IVAE_OK;
+}
+
+static int check_coef(const IvaeDims* dims, const IvaeCoef* c) {
+    if (!c) return IVAE_E_NULLPTR;
+    if (c->global_batch < dims->batch || !(c->decoder_var > 0.f)) return IVAE_E_BADDIMS;
+    if (c->pairwise && !(c->dataset_size > 0.f)) return IVAE_E_BADDIMS;
+    return IVAE_OK;
+}
+
+int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
+                 const float* eps, float* z_out, void* workspace, size_t workspace_bytes, void* stream) {
+    Layout L;
+    int rc = ivae_make_layout(dims, &L);
+    if (rc) return rc;
+    if ((rc = check_coef(dims, coef))) return rc;
+    if (!params || !x || !eps || !z_out || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
+    if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
+    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_forward");
+}
+
+int ivae_pairwise(int32_t n_rows, int32_t n_cols, int32_t latent_dim, const IvaeCoef* coef, const float* z,
+                  const float* g_cols, const float* v_cols, float* lq, float* lqi, float* lse_s, float* lse_k,
+                  float* rz, float* cg, float* cv, void* stream) {
+    if (n_rows <= 0 || n_cols <= 0 || latent_dim <= 0) return IVAE_E_BADDIMS;
+    if (latent_dim > 64) return IVAE_E_TOOLARGE;
+    if (!coef || !z || !g_cols || !v_cols || !lq || !lqi || !lse_s || !lse_k || !rz || !cg || !cv) return IVAE_E_NULLPTR;
+    if (!(coef->dataset_size > 0.f) || coef->global_batch <= 0) return IVAE_E_BADDIMS;
+    hipError_t e = launch_pairwise(n_rows, n_cols, latent_dim, *coef, z, g_cols, v_cols, lq, lqi, lse_s, lse_k, rz, cg,
+                                   cv, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_pairwise");
+}
+
+int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
+                  const float* eps, float* loss_out, float* grads, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    Layout L;
+    int rc = ivae_make_layout(dims, &L);
+    if (rc) return rc;
+    if ((rc = check_coef(dims, coef))) return rc;
+    if (!params || !x || !eps || !grads || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
+    if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
+    hipError_t e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_backward");
+}
+
+int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
+                      const float* eps, float* z_out, float* loss_out, float* grads, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    int rc = ivae_forward(dims, coef, params, x, u, eps, z_out, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    if (coef->pairwise) {
+        if (coef->global_batch != dims->batch) return IVAE_E_BADDIMS;   // DP callers run the phases themselves
+        Layout L;
+        ivae_make_layout(dims, &L);
+        for (int m = 0; m < L.n_models; ++m) {
+            float* w = (float*)workspace + (size_t)m * L.ws.per_model;
+            rc = ivae_pairwise(L.B, L.B, L.dl, coef, w + L.ws.z, w + L.ws.g, w + L.ws.v, w + L.ws.lq, w + L.ws.lqi,
+                               w + L.ws.lse_s, w + L.ws.lse_k, w + L.ws.rz, w + L.ws.cg, w + L.ws.cv, stream);
+            if (rc) return rc;
+        }
+    }
+    return ivae_backward(dims, coef, params, x, u, eps, loss_out, grads, workspace, workspace_bytes, stream);
+}
+
+int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float* grads, int64_t n, float lr,
+                   float beta1, float beta2, float eps, int64_t step, void* stream) {
+    if (!params || !exp_avg || !exp_avg_sq || !grads) return IVAE_E_NULLPTR;
+    if (n <= 0 || step < 1) return IVAE_E_BADDIMS;
+    hipError_t e = launch_adam(params, exp_avg, exp_avg_sq, grads, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_adam_step");
+}
+
+int ivae_corr_workspace_bytes(int64_t n, int32_t d, size_t* out) {
+    if (!out) return IVAE_E_NULLPTR;
+    if (n < 2 || d <= 0) return IVAE_E_BADDIMS;
+    if (d > 64) return IVAE_E_TOOLARGE;
+    *out = corr_ws_bytes(n, d);
+    return IVAE_OK;
+}
+
+int ivae_corr(const float* x, const float* y, int64_t n, int32_t d, double* cc_out, void* workspace,
+              size_t workspace_bytes, void* stream) {
+    if (!x || !y || !cc_out || !workspace) return IVAE_E_NULLPTR;
+    if (n < 2 || d <= 0) return IVAE_E_BADDIMS;
+    if (d > 64) return IVAE_E_TOOLARGE;
+    if (workspace_bytes < corr_ws_bytes(n, d)) return IVAE_E_WORKSPACE;
+    hipError_t e = launch_corr(x, y, n, d, cc_out, (double*)workspace, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_corr");
+}
+
+}  // extern "C"

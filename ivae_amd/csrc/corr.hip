@@ -1,0 +1,118 @@
+// Pearson cross-correlation block for the MCC metric, float64 arithmetic on fp32 inputs.
+//
+// Replaces np.corrcoef(x, y, rowvar=False)[:d, d:] (metrics/mcc.py:328; torch spec at
+// mcc.py:174-253): two-pass centred moments.  Pass 1: column sums -> means.  Pass 2: centred
+// cross/auto moments, 64-row chunks staged in LDS as doubles, per-block partials reduced in a
+// fixed order (bitwise reproducible).  The Hungarian step (mcc.py:334) stays on the host.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+#define CORR_BLOCKS 256
+#define CORR_ROWS 64
+
+size_t corr_ws_bytes(int64_t n, int d) {
+    (void)n;
+    return sizeof(double) * ((size_t)2 * d + (size_t)CORR_BLOCKS * 2 * d + (size_t)CORR_BLOCKS * ((size_t)d * d + 2 * d));
+}
+
+__global__ __launch_bounds__(256) void k_corr_sums(const float* __restrict__ x, const float* __restrict__ y,
+                                                   int64_t n, int d, double* __restrict__ psum) {
+    // thread c < 2d owns a column; rows strided over blocks.  (d is small: <= 64.)
+    __shared__ double red[256];
+    const int c = threadIdx.x % (2 * d);
+    const int sub = threadIdx.x / (2 * d);
+    const int nsub = 256 / (2 * d);
+    double acc = 0.0;
+    if (sub < nsub) {
+        const float* src = c < d ? x + c : y + (c - d);
+        for (int64_t r = (int64_t)blockIdx.x * nsub + sub; r < n; r += (int64_t)gridDim.x * nsub) acc += (double)src[r * d];
+    }
+    red[threadIdx.x] = sub < nsub ? acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x < 2 * d) {
+        double t = 0.0;
+        for (int s = 0; s < nsub; ++s) t += red[s * 2 * d + threadIdx.x];
+        psum[(size_t)blockIdx.x * 2 * d + threadIdx.x] = t;
+    }
+}
+
+__global__ void k_corr_mean(const double* __restrict__ psum, int64_t n, int d, int nblk, double* __restrict__ mean) {
+    const int c = threadIdx.x;
+    if (c < 2 * d) {
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += psum[(size_t)b * 2 * d + c];
+        mean[c] = t / (double)n;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_corr_moments(const float* __restrict__ x, const float* __restrict__ y,
+                                                      int64_t n, int d, const double* __restrict__ mean,
+                                                      double* __restrict__ pmom) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];   // CORR_ROWS x (2d+1)
+    const int ld = 2 * d + 1;
+    const int nout = d * d + 2 * d;
+    // every thread keeps up to ceil(nout/256) accumulators; nout <= 64*64+128 -> <= 17
+    double acc[17];
+#pragma unroll
+    for (int q = 0; q < 17; ++q) acc[q] = 0.0;
+    for (int64_t r0 = (int64_t)blockIdx.x * CORR_ROWS; r0 < n; r0 += (int64_t)gridDim.x * CORR_ROWS) {
+        const int nr = (int)((n - r0) < CORR_ROWS ? (n - r0) : CORR_ROWS);
+        for (int idx = threadIdx.x; idx < CORR_ROWS * 2 * d; idx += 256) {
+            const int r = idx / (2 * d), c = idx - r * 2 * d;
+            double val = 0.0;
+            if (r < nr) val = (c < d ? (double)x[(r0 + r) * d + c] : (double)y[(r0 + r) * d + (c - d)]) - mean[c];
+            tile[r * ld + c] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 17; ++q) {
+            const int o = threadIdx.x + q * 256;
+            if (o < nout) {
+                int ca, cb;
+                if (o < d * d) { ca = o / d; cb = d + (o - ca * d); }
+                else { ca = cb = o - d * d; }
+                double s = 0.0;
+                for (int r = 0; r < nr; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
+                acc[q] += s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 17; ++q) {
+        const int o = threadIdx.x + q * 256;
+        if (o < nout) pmom[(size_t)blockIdx.x * nout + o] = acc[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_corr_final(const double* __restrict__ pmom, int64_t n, int d, int nblk,
+                                                    double* __restrict__ cc) {
+    extern __shared__ __attribute__((aligned(16))) double mom[];   // d*d + 2d
+    const int nout = d * d + 2 * d;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        double t = 0.0;
+        for (int b = 0; b < nblk; ++b) t += pmom[(size_t)b * nout + o];
+        mom[o] = t / (double)(n - 1);        // np.cov normalisation (cancels, kept for rounding parity)
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < d * d; o += 256) {
+        const int a = o / d, b = o - a * d;
+        double c = mom[o] / sqrt(mom[d * d + a]);
+        c = c / sqrt(mom[d * d + d + b]);
+        cc[o] = fmin(1.0, fmax(-1.0, c));     // np.corrcoef clips to [-1, 1]
+    }
+}
+
+hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st) {
+    double* mean = ws;
+    double* psum = mean + 2 * d;
+    double* pmom = psum + (size_t)CORR_BLOCKS * 2 * d;
+    int nblk = (int)((n + CORR_ROWS - 1) / CORR_ROWS);
+    if (nblk > CORR_BLOCKS) nblk = CORR_BLOCKS;
+    hipLaunchKernelGGL(k_corr_sums, dim3(nblk), dim3(256), 0, st, x, y, n, d, psum);
+    hipLaunchKernelGGL(k_corr_mean, dim3(1), dim3(128), 0, st, psum, n, d, nblk, mean);
+    hipLaunchKernelGGL(k_corr_moments, dim3(nblk), dim3(256), (size_t)CORR_ROWS * (2 * d + 1) * sizeof(double), st, x, y,
+                       n, d, mean, pmom);
+    hipLaunchKernelGGL(k_corr_final, dim3(1), dim3(256), (size_t)(d * d + 2 * d) * sizeof(double), st, pmom, n, d, nblk, cc);
+    return hipGetLastError();
+}

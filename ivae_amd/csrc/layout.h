@@ -1,0 +1,94 @@
+// Parameter-arena and workspace layout shared by host launchers and kernels.
+#pragma once
+#include <stdint.h>
+#include "../../include/ivae_amd.h"
+
+#define IVAE_MAX_LAYERS 8
+#define IVAE_MLP_LOGL 0
+#define IVAE_MLP_F 1
+#define IVAE_MLP_G 2
+#define IVAE_MLP_LOGV 3
+
+struct MlpDesc {
+    int present;
+    int in_dim, out_dim;
+    int w_off[IVAE_MAX_LAYERS];    // float offset of layer weight (out,in) inside a model's arena
+    int b_off[IVAE_MAX_LAYERS];
+    int din[IVAE_MAX_LAYERS];
+    int dout[IVAE_MAX_LAYERS];
+    int64_t pre_off[IVAE_MAX_LAYERS];  // workspace offset of hidden pre-activations (batch, hidden)
+};
+
+struct Layout {
+    int B, dd, dl, M, H, L, act, n_models;
+    float slope;
+    int n_params;
+    MlpDesc mlp[4];
+    int maxw;            // widest activation row (inputs included)
+    int maxh;            // widest row among hidden / output tensors
+    // workspace (float offsets per model)
+    IvaeWsLayout ws;
+    int64_t ws_partial;  // (n_tiles_bwd, n_params) per-tile gradient slabs
+    int tr_fwd, tr_bwd;  // rows per workgroup
+    int n_tiles_fwd, n_tiles_bwd;
+};
+
+static inline int ivae_check_dims(const IvaeDims* d) {
+    if (!d) return IVAE_E_NULLPTR;
+    if (d->batch <= 0 || d->data_dim <= 0 || d->latent_dim <= 0 || d->aux_dim < 0 || d->n_models <= 0)
+        return IVAE_E_BADDIMS;
+    if (d->n_layers < 1 || d->n_layers > IVAE_MAX_LAYERS) return IVAE_E_BADDIMS;
+    if (d->n_layers > 1 && d->hidden_dim <= 0) return IVAE_E_BADDIMS;
+    if (d->activation < IVAE_ACT_NONE || d->activation > IVAE_ACT_SIGMOID) return IVAE_E_BADACT;
+    if (d->latent_dim > 64 || d->data_dim > 1024 || d->aux_dim > 4096 || d->hidden_dim > 1024)
+        return IVAE_E_TOOLARGE;
+    return IVAE_OK;
+}
+
+static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
+    int rc = ivae_check_dims(d);
+    if (rc) return rc;
+    Layout& L = *Lo;
+    L.B = d->batch; L.dd = d->data_dim; L.dl = d->latent_dim; L.M = d->aux_dim;
+    L.H = d->n_layers > 1 ? d->hidden_dim : 0; L.L = d->n_layers; L.act = d->activation;
+    L.slope = d->slope; L.n_models = d->n_models;
+    int off = 0;
+    int64_t wso = 0;
+    for (int m = 0; m < 4; ++m) {
+        MlpDesc& D = L.mlp[m];
+        D.present = (m != IVAE_MLP_LOGL) || (L.M > 0);
+        if (m == IVAE_MLP_LOGL) { D.in_dim = L.M; D.out_dim = L.dl; }
+        else if (m == IVAE_MLP_F) { D.in_dim = L.dl; D.out_dim = L.dd; }
+        else { D.in_dim = L.dd + L.M; D.out_dim = L.dl; }
+        for (int li = 0; li < IVAE_MAX_LAYERS; ++li) { D.w_off[li] = D.b_off[li] = D.din[li] = D.dout[li] = 0; D.pre_off[li] = 0; }
+        if (!D.present) continue;
+        for (int li = 0; li < L.L; ++li) {
+            D.din[li] = li == 0 ? D.in_dim : L.H;
+            D.dout[li] = li == L.L - 1 ? D.out_dim : L.H;
+            D.w_off[li] = off; off += D.din[li] * D.dout[li];
+            D.b_off[li] = off; off += D.dout[li];
+            if (li < L.L - 1) { D.pre_off[li] = wso; wso += (int64_t)L.B * L.H; }
+        }
+    }
+    L.n_params = off;
+    L.maxh = L.H; if (L.dd > L.maxh) L.maxh = L.dd; if (L.dl > L.maxh) L.maxh = L.dl;
+    L.maxw = L.maxh; if (L.dd + L.M > L.maxw) L.maxw = L.dd + L.M;
+    auto take = [&](int64_t n) { int64_t o = wso; wso += n; return o; };
+    int64_t Bl = (int64_t)L.B * L.dl;
+    L.ws.g = take(Bl); L.ws.v = take(Bl); L.ws.l = take(Bl); L.ws.z = take(Bl);
+    L.ws.f = take((int64_t)L.B * L.dd);
+    L.ws.lpx = take(L.B); L.ws.lqc = take(L.B); L.ws.lp = take(L.B); L.ws.lq = take(L.B); L.ws.lqi = take(L.B);
+    L.ws.rz = take(Bl); L.ws.cg = take(Bl); L.ws.cv = take(Bl);
+    L.ws.lse_s = take(L.B); L.ws.lse_k = take(Bl);
+    // rows per workgroup: keep the LDS tiles under ~60 KB
+    int ldf = L.maxw + 1, ldb = L.maxh + 1;
+    L.tr_fwd = 64; while (L.tr_fwd > 8 && (int64_t)L.tr_fwd * (3 * ldf + 4 * (L.dl + 1)) * 4 > 60 * 1024) L.tr_fwd >>= 1;
+    L.tr_bwd = 64; while (L.tr_bwd > 8 && (int64_t)L.tr_bwd * (3 * ldb + 4 * (L.dl + 1)) * 4 > 60 * 1024) L.tr_bwd >>= 1;
+    if ((int64_t)L.tr_fwd * (3 * ldf + 4 * (L.dl + 1)) * 4 > 60 * 1024) return IVAE_E_TOOLARGE;
+    L.n_tiles_fwd = (L.B + L.tr_fwd - 1) / L.tr_fwd;
+    L.n_tiles_bwd = (L.B + L.tr_bwd - 1) / L.tr_bwd;
+    L.ws_partial = take((int64_t)L.n_tiles_bwd * L.n_params);
+    wso = (wso + 63) & ~(int64_t)63;
+    L.ws.per_model = wso;
+    return IVAE_OK;
+}

@@ -1,0 +1,207 @@
+"""Tensor-level entry points over the C ABI.  PyTorch supplies device memory and the
+stream; every computation below happens in libivae_amd.so's HIP kernels."""
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import ACT_IDS, IvaeCoef, IvaeDims, IvaeWsLayout, check
+
+
+@dataclass(frozen=True)
+class ModelShape:
+    """Static shape of a model (constructor arguments of models/nets.py:125,190,392,550)."""
+    data_dim: int
+    latent_dim: int
+    aux_dim: int            # 0: VAE family
+    hidden_dim: int
+    n_layers: int
+    activation: str
+    slope: float
+
+    def dims(self, batch, n_models=1):
+        if self.activation not in ACT_IDS:
+            raise ValueError("Incorrect activation: {}".format(self.activation))
+        return IvaeDims(batch, self.data_dim, self.latent_dim, self.aux_dim, self.hidden_dim, self.n_layers,
+                        ACT_IDS[self.activation], float(self.slope), n_models)
+
+    @property
+    def mlps(self):
+        return ("logl", "f", "g", "logv") if self.aux_dim > 0 else ("f", "g", "logv")
+
+    def mlp_io(self, name):
+        if name == "logl":
+            return self.aux_dim, self.latent_dim
+        if name == "f":
+            return self.latent_dim, self.data_dim
+        return self.data_dim + self.aux_dim, self.latent_dim
+
+    def n_params(self):
+        n = C.c_int64()
+        check(_lib.lib().ivae_param_count(C.byref(self.dims(1)), C.byref(n)), "ivae_param_count")
+        return n.value
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a ROCm device: ivae_amd has no CPU path")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def make_coef(a=1., b=1., c=1., d=1., N=1., decoder_var=.01, pairwise=False, global_batch=1):
+    return IvaeCoef(float(a), float(b), float(c), float(d), float(N), float(decoder_var), int(bool(pairwise)),
+                    int(global_batch))
+
+
+def workspace_bytes(dims):
+    n = C.c_size_t()
+    check(_lib.lib().ivae_workspace_bytes(C.byref(dims), C.byref(n)), "ivae_workspace_bytes")
+    return n.value
+
+
+def workspace_layout(dims):
+    lay = IvaeWsLayout()
+    check(_lib.lib().ivae_workspace_layout(C.byref(dims), C.byref(lay)), "ivae_workspace_layout")
+    return lay
+
+
+class Workspace:
+    """Caller-owned scratch for one (shape, batch, n_models); grows on demand."""
+
+    def __init__(self):
+        self.buf = None
+        self.key = None
+        self.layout = None
+
+    def get(self, dims, device):
+        key = tuple(getattr(dims, f) for f, _ in dims._fields_) + (str(device),)
+        if key != self.key:
+            nbytes = workspace_bytes(dims)
+            if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != device:
+                self.buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+            self.layout = workspace_layout(dims)
+            self.key = key
+        return self.buf
+
+    def view(self, name, batch, width=None, model=0):
+        """Row tensor `name` of the last call as a (batch[, width]) view."""
+        off = getattr(self.layout, name) + model * self.layout.per_model
+        n = batch * (width or 1)
+        t = self.buf[off:off + n]
+        return t.view(batch, width) if width else t
+
+
+def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1):
+    """ivae_elbo_fwd_bwd: -> (loss (n_models,), z, grads flat like params)."""
+    x = _f32c(x, "x")
+    eps = _f32c(eps, "eps")
+    params = _f32c(params, "params")
+    if shape.aux_dim > 0:
+        u = _f32c(u, "u")
+    else:
+        u = None
+    B = x.shape[-2]
+    dims = shape.dims(B, n_models)
+    dev = x.device
+    with torch.cuda.device(dev):
+        buf = ws.get(dims, dev)
+        z = torch.empty(x.shape[:-1] + (shape.latent_dim,), dtype=torch.float32, device=dev)
+        loss = torch.empty(n_models, dtype=torch.float32, device=dev)
+        grads = torch.empty_like(params)
+        check(_lib.lib().ivae_elbo_fwd_bwd(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps),
+                                           _ptr(z), _ptr(loss), _ptr(grads), _ptr(buf), buf.numel() * 4,
+                                           _stream(dev)), "ivae_elbo_fwd_bwd")
+    return loss, z, grads
+
+
+def forward(shape, coef, params, x, u, eps, ws, n_models=1):
+    """ivae_forward: fills the workspace row tensors, returns z."""
+    x = _f32c(x, "x")
+    eps = _f32c(eps, "eps")
+    params = _f32c(params, "params")
+    u = _f32c(u, "u") if shape.aux_dim > 0 else None
+    B = x.shape[-2]
+    dims = shape.dims(B, n_models)
+    dev = x.device
+    with torch.cuda.device(dev):
+        buf = ws.get(dims, dev)
+        z = torch.empty(x.shape[:-1] + (shape.latent_dim,), dtype=torch.float32, device=dev)
+        check(_lib.lib().ivae_forward(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps), _ptr(z),
+                                      _ptr(buf), buf.numel() * 4, _stream(dev)), "ivae_forward")
+    return z
+
+
+def pairwise(coef, z, g_cols, v_cols):
+    """ivae_pairwise on explicit row/column tensors -> dict of outputs (single model)."""
+    z, g_cols, v_cols = _f32c(z, "z"), _f32c(g_cols, "g"), _f32c(v_cols, "v")
+    n_rows, d = z.shape
+    n_cols = g_cols.shape[0]
+    dev = z.device
+    mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = dict(lq=mk(n_rows), lqi=mk(n_rows), lse_s=mk(n_rows), lse_k=mk(n_rows, d), rz=mk(n_rows, d),
+               cg=mk(n_cols, d), cv=mk(n_cols, d))
+    with torch.cuda.device(dev):
+        check(_lib.lib().ivae_pairwise(n_rows, n_cols, d, C.byref(coef), _ptr(z), _ptr(g_cols), _ptr(v_cols),
+                                       _ptr(out["lq"]), _ptr(out["lqi"]), _ptr(out["lse_s"]), _ptr(out["lse_k"]),
+                                       _ptr(out["rz"]), _ptr(out["cg"]), _ptr(out["cv"]), _stream(dev)),
+              "ivae_pairwise")
+    return out
+
+
+def backward(shape, coef, params, x, u, eps, ws, n_models=1):
+    """ivae_backward after forward (+pairwise results copied into the workspace)."""
+    x = _f32c(x, "x")
+    eps = _f32c(eps, "eps")
+    u = _f32c(u, "u") if shape.aux_dim > 0 else None
+    B = x.shape[-2]
+    dims = shape.dims(B, n_models)
+    dev = x.device
+    with torch.cuda.device(dev):
+        buf = ws.get(dims, dev)
+        loss = torch.empty(n_models, dtype=torch.float32, device=dev)
+        grads = torch.empty_like(params)
+        check(_lib.lib().ivae_backward(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps),
+                                       _ptr(loss), _ptr(grads), _ptr(buf), buf.numel() * 4, _stream(dev)),
+              "ivae_backward")
+    return loss, grads
+
+
+def adam_step(params, exp_avg, exp_avg_sq, grads, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """ivae_adam_step in place over flat contiguous fp32 tensors."""
+    for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (grads, "grads")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"{n} must be a contiguous float32 ROCm tensor")
+    dev = params.device
+    with torch.cuda.device(dev):
+        check(_lib.lib().ivae_adam_step(_ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(grads), params.numel(),
+                                        float(lr), float(beta1), float(beta2), float(eps), int(step), _stream(dev)),
+              "ivae_adam_step")
+
+
+def corr(x, y):
+    """ivae_corr: float64 (d,d) cross-correlation block of fp32 (n,d) tensors, on device."""
+    x, y = _f32c(x, "x"), _f32c(y, "y")
+    if x.shape != y.shape or x.dim() != 2:
+        raise ValueError("x and y have different shapes")
+    n, d = x.shape
+    dev = x.device
+    nb = C.c_size_t()
+    check(_lib.lib().ivae_corr_workspace_bytes(n, d, C.byref(nb)), "ivae_corr_workspace_bytes")
+    with torch.cuda.device(dev):
+        ws = torch.empty((nb.value + 7) // 8, dtype=torch.float64, device=dev)
+        cc = torch.empty(d, d, dtype=torch.float64, device=dev)
+        check(_lib.lib().ivae_corr(_ptr(x), _ptr(y), n, d, _ptr(cc), _ptr(ws), ws.numel() * 8, _stream(dev)),
+              "ivae_corr")
+    return cc

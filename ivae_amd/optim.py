@@ -1,0 +1,75 @@
+"""Fused Adam: one HIP launch per step over the model's flat parameter arena.
+
+Counterpart of ``optim.Adam(model.parameters(), lr=...)`` (runners/ivae.py:38, wrappers.py:44,127)
+with torch's defaults (betas (.9,.999), eps 1e-8, no weight decay, no amsgrad).  ``lr`` is read
+from ``param_groups`` at every step, so ``ReduceLROnPlateau`` keeps working, and
+``state_dict()`` has torch.optim.Adam's layout (per-parameter ``step``, ``exp_avg``,
+``exp_avg_sq``), so ``utils.checkpoint`` (utils/utils.py:55-64) is unchanged.
+"""
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @staticmethod
+    def _flat_view(tensors):
+        """If `tensors` tile one contiguous buffer in order, return it as a flat view."""
+        if not tensors:
+            return None
+        first = tensors[0]
+        ptr, total = first.data_ptr(), 0
+        for t in tensors:
+            if not t.is_contiguous() or t.dtype != torch.float32 or t.data_ptr() != ptr + 4 * total:
+                return None
+            total += t.numel()
+        storage_off = first.storage_offset()
+        if first.untyped_storage().nbytes() < 4 * (storage_off + total):
+            return None
+        return torch.as_strided(first, (total,), (1,), storage_off)
+
+    def _init_group_state(self, ps):
+        total = sum(p.numel() for p in ps)
+        m = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
+        v = torch.zeros_like(m)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            st = self.state[p]
+            st['step'] = torch.tensor(0.)
+            st['exp_avg'] = m[off:off + n].view(p.shape)
+            st['exp_avg_sq'] = v[off:off + n].view(p.shape)
+            off += n
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            ps = [p for p in group['params'] if p.grad is not None]
+            if not ps:
+                continue
+            if any(len(self.state[p]) == 0 for p in ps):
+                self._init_group_state(ps)
+            b1, b2 = group['betas']
+            for p in ps:
+                self.state[p]['step'] += 1
+            step = int(self.state[ps[0]]['step'])
+            flat_p = self._flat_view([p.data for p in ps])
+            flat_g = self._flat_view([p.grad for p in ps])
+            flat_m = self._flat_view([self.state[p]['exp_avg'] for p in ps])
+            flat_v = self._flat_view([self.state[p]['exp_avg_sq'] for p in ps])
+            if all(t is not None for t in (flat_p, flat_g, flat_m, flat_v)):
+                ops.adam_step(flat_p, flat_m, flat_v, flat_g, group['lr'], step, b1, b2, group['eps'])
+            else:   # parameters not backed by one arena: one launch per tensor, same kernel
+                for p in ps:
+                    st = self.state[p]
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    ops.adam_step(p.data.view(-1), st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1), g.view(-1),
+                                  group['lr'], int(st['step']), b1, b2, group['eps'])
+        return loss

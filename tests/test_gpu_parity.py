@@ -1,0 +1,287 @@
+"""GPU parity tests: HIP path (through the C ABI) vs golden vectors from the reference and
+vs the CPU oracle.  Tolerances: 1e-5 relative for loss and forward tensors; gradients 1e-5
+per-tensor max-norm relative (north_star), written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+import ivae_amd
+from ivae_amd import ops
+from oracle import np_ref
+from tests.test_api_cpu import _build
+from tests.util import Case, case_names, relmax
+
+pytestmark = pytest.mark.gpu
+
+CASES = case_names()
+TOL = 1e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def shape_of(c):
+    s = c.spec
+    return ops.ModelShape(s.data_dim, s.latent_dim, s.aux_dim, s.hidden_dim, s.n_layers, s.activation, s.slope)
+
+
+def flat(group, names):
+    return np.concatenate([group[n].reshape(-1) for n in names])
+
+
+def coef_of(c, step, B):
+    co = c.coef(step)
+    return ops.make_coef(co.a, co.b, co.c, co.d, co.N, c.spec.decoder_var, co.pairwise, B)
+
+
+def run_case(c, step=0, params=None):
+    d = dev()
+    names = c.spec.param_names()
+    x, u, eps = c.inputs(step)
+    P = flat(c.params, names) if params is None else params
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    ws = ops.Workspace()
+    loss, z, grads = ops.elbo_fwd_bwd(shape_of(c), coef_of(c, step, x.shape[0]), t(P), t(x),
+                                      t(u) if c.spec.aux_dim else None, t(eps), ws)
+    torch.cuda.synchronize()
+    return loss, z, grads, ws
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_elbo_and_grads_match_reference_fixture(name):
+    c = Case(name)
+    names = c.spec.param_names()
+    loss, z, grads, ws = run_case(c)
+    B = c.meta["batch"]
+    assert abs(float(loss[0]) - c.loss()) <= TOL * abs(c.loss())
+    assert relmax(z.cpu().numpy(), c.z["z"]) < TOL
+    for k, w in (("g", c.spec.latent_dim), ("v", c.spec.latent_dim), ("l", c.spec.latent_dim), ("f", c.spec.data_dim)):
+        assert relmax(ws.view(k, B, w).cpu().numpy(), c.z[k]) < TOL, k
+    for k in ("lpx", "lqc", "lp"):
+        assert relmax(ws.view(k, B).cpu().numpy(), c.z[k]) < TOL, k
+    g = grads.cpu().numpy()
+    off = 0
+    for n in names:
+        ref = c.grads[n]
+        got = g[off:off + ref.size].reshape(ref.shape)
+        off += ref.size
+        assert relmax(got, ref) < TOL, (n, relmax(got, ref))
+    assert off == g.size
+
+
+@pytest.mark.parametrize("name", ["ivae_plain_cfg2", "cleanivae_cfg1", "cleanvae_btcvae_b200", "ivae_anneal_cfg2"])
+def test_against_fp64_oracle(name):
+    """Same inputs through oracle/np_ref in float64: tighter than the fp32 fixture."""
+    c = Case(name)
+    x, u, eps = c.inputs()
+    fw = np_ref.elbo_forward(c.params, x, u, eps, c.spec, c.coef(), np.float64)
+    G = np_ref.elbo_backward(c.params, x, u, fw, c.spec, c.coef(), np.float64)
+    loss, z, grads, ws = run_case(c)
+    assert abs(float(loss[0]) - float(fw["loss"])) <= 3e-6 * abs(float(fw["loss"]))
+    g = grads.cpu().numpy()
+    off = 0
+    for n in c.spec.param_names():
+        ref = G[n]
+        assert relmax(g[off:off + ref.size].reshape(ref.shape), ref) < 5e-6, n
+        off += ref.size
+    if c.coef().pairwise:
+        B = c.meta["batch"]
+        assert relmax(ws.view("lq", B).cpu().numpy(), fw["lq"]) < 3e-6
+        assert relmax(ws.view("lqi", B).cpu().numpy(), fw["lqi"]) < 3e-6
+
+
+def test_results_are_bitwise_reproducible():
+    c = Case("cleanivae_lrelu_b70")
+    a = run_case(c)
+    b = run_case(c)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("name", ["ivae_plain_cfg2", "ivae_plain_tiny", "cleanvae_tiny"])
+def test_adam_kernel_matches_torch_adam(name):
+    """ivae_adam_step on the fixture's own gradient == torch.optim.Adam's first step."""
+    c = Case(name)
+    d = dev()
+    names = c.spec.param_names()
+    p = torch.from_numpy(flat(c.params, names)).to(d)
+    g = torch.from_numpy(flat(c.grads, names)).to(d)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    ops.adam_step(p, m, v, g, 1e-2, 1)
+    assert np.abs(p.cpu().numpy() - flat(c.group("adam1.p."), names)).max() < 1e-7
+    assert relmax(m.cpu().numpy(), flat(c.group("adam1.m."), names)) < 1e-6
+    assert relmax(v.cpu().numpy(), flat(c.group("adam1.v."), names)) < 1e-6
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_module_training_trajectory(name):
+    """Drop-in module + FusedAdam reproduce the reference's 4-step trajectory
+    (3 steps at lr 1e-2, lr drop to 1e-3, 1 step): elbo -> backward -> step."""
+    c = Case(name)
+    d = dev()
+    model = _build(c)
+    if c.family == "iVAE" and any(s["pairwise"] for s in c.meta["steps"]):
+        model.anneal_params = True
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in c.params.items()})
+    model = model.to(d)
+    opt = ivae_amd.FusedAdam(model.parameters(), lr=1e-2)
+    anneal_it = {"ivae_anneal_tiny": 300, "ivae_anneal_cfg2": 1, "ivae_anneal_switch": 623}.get(name)
+    for k in range(4):
+        if k == 3:
+            for grp in opt.param_groups:
+                grp["lr"] = 1e-3
+        x, u, eps = (torch.from_numpy(t).to(d) for t in c.inputs(k))
+        co = c.coef(k)
+        opt.zero_grad()
+        if c.family == "iVAE":
+            if anneal_it is not None:
+                model.anneal(c.meta["N"], 1000, anneal_it + k)
+            elbo, z = model.elbo(x, u, eps=eps)
+            loss = elbo.mul(-1)
+        elif c.family == "VAE":
+            elbo, z = model.elbo(x, eps=eps)
+            loss = elbo.mul(-1)
+        else:
+            loss, z = model.elbo(x, u, c.meta["N"], a=co.a, b=co.b, c=co.c, d=co.d, eps=eps)
+        loss.backward()
+        # losses after the first step see parameters that already differ at the 1e-6 level
+        assert abs(loss.item() - c.loss(k)) <= (TOL if k == 0 else 2e-3) * abs(c.loss(k)), k
+        if k == 0:
+            for n, p in model.named_parameters():
+                assert relmax(p.grad.cpu().numpy(), c.grads[n]) < TOL, n
+        opt.step()
+        if c.has_adam(k + 1):
+            for n, p in model.named_parameters():
+                ref = c.z[f"adam{k+1}.p.{n}"]
+                tol = 1e-6 if k == 0 else 2e-2 * c.meta["lrs"][k]
+                assert np.abs(p.detach().cpu().numpy() - ref).max() < tol, (k, n)
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    assert int(sd["state"][0]["step"]) == 4
+
+
+def test_module_works_with_stock_torch_adam_and_forward():
+    """runners/ivae.py:38 uses torch.optim.Adam on model.parameters(): must keep working, and
+    forward() must return the reference's tuple structure."""
+    c = Case("ivae_plain_cfg2")
+    d = dev()
+    model = _build(c)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in c.params.items()})
+    model = model.to(d)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    x, u, eps = (torch.from_numpy(t).to(d) for t in c.inputs(0))
+    elbo, z = model.elbo(x, u, eps=eps)
+    elbo.mul(-1).backward()
+    opt.step()
+    for n, p in model.named_parameters():
+        assert np.abs(p.detach().cpu().numpy() - c.z[f"adam1.p.{n}"]).max() < 1e-6, n
+    (f, dv), (g, v), z2, (pm, l) = model(x, u, eps=eps)
+    assert f.shape == (64, 10) and g.shape == v.shape == z2.shape == l.shape == (64, 10)
+    assert float(dv) == pytest.approx(0.01)
+    # without eps the module draws its own noise
+    e1, z1 = model.elbo(x, u)
+    assert torch.isfinite(e1) and z1.shape == (64, 10)
+
+
+def test_pairwise_rectangular_matches_oracle():
+    """Rows != columns (the data-parallel shard shape): ivae_pairwise vs explicit numpy."""
+    rng = np.random.RandomState(3)
+    nr, nc, d = 37, 101, 6
+    z = rng.randn(nr, d).astype(np.float32)
+    g = rng.randn(nc, d).astype(np.float32)
+    v = np.exp(0.3 * rng.randn(nc, d)).astype(np.float32)
+    co = ops.make_coef(2., 3., 1.5, .5, 40000., .1, True, nc)
+    out = ops.pairwise(co, *(torch.from_numpy(t).to(dev()) for t in (z, g, v)))
+    z64, g64, v64 = (t.astype(np.float64) for t in (z, g, v))
+    T = np_ref.log_normal(z64[:, None, :], g64[None], v64[None], np.log(2 * np.pi))
+    S = T.sum(-1)
+    lse_s = np_ref.logsumexp(S, 1)
+    lse_k = np_ref.logsumexp(T, 1)
+    logMN = np.log(nc * 40000.)
+    Wt = (3. - 1.5) * np.exp(S - lse_s[:, None])[:, :, None] + (1.5 - .5) * np.exp(T - lse_k[:, None, :])
+    diff = z64[:, None, :] - g64[None]
+    rij = diff / v64[None]
+    ref = dict(lq=lse_s - logMN, lqi=(lse_k - logMN).sum(-1), lse_s=lse_s, lse_k=lse_k, rz=(Wt * -rij).sum(1),
+               cg=(Wt * rij).sum(0), cv=(Wt * -0.5 * (1 - diff * rij)).sum(0))
+    for k, r in ref.items():
+        assert relmax(out[k].cpu().numpy(), r) < 5e-6, k
+
+
+def test_packed_models_equal_individual_runs():
+    """n_models=3 in one launch == three single-model launches (config-5 packing)."""
+    c = Case("ivae_plain_b70")
+    d = dev()
+    names = c.spec.param_names()
+    rng = np.random.RandomState(0)
+    P0 = flat(c.params, names)
+    Ps = np.stack([P0, P0 + 0.01 * rng.randn(P0.size).astype(np.float32), P0 * 0.9])
+    xs = np.stack([c.inputs(k)[0] for k in range(3)])
+    us = np.stack([c.inputs(k)[1] for k in range(3)])
+    es = np.stack([c.inputs(k)[2] for k in range(3)])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    co = coef_of(c, 0, 70)
+    loss, z, grads = ops.elbo_fwd_bwd(shape_of(c), co, t(Ps), t(xs), t(us), t(es), ops.Workspace(), n_models=3)
+    for m in range(3):
+        l1, z1, g1 = ops.elbo_fwd_bwd(shape_of(c), co, t(Ps[m]), t(xs[m]), t(us[m]), t(es[m]), ops.Workspace())
+        assert torch.equal(l1[0], loss[m]) and torch.equal(z1, z[m]) and torch.equal(g1, grads[m])
+
+
+def test_data_parallel_shards_sum_to_full_batch():
+    """Row shards with global_batch = B: partial losses / grads add up to the full-batch result."""
+    c = Case("ivae_plain_cfg4s")
+    d = dev()
+    names = c.spec.param_names()
+    x, u, eps = c.inputs()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    P = t(flat(c.params, names))
+    B = x.shape[0]
+    co = coef_of(c, 0, B)
+    full = ops.elbo_fwd_bwd(shape_of(c), co, P, t(x), t(u), t(eps), ops.Workspace())
+    acc_l, acc_g = 0., 0.
+    for lo, hi in ((0, 40), (40, 96)):
+        l, z, g = ops.elbo_fwd_bwd(shape_of(c), co, P, t(x[lo:hi]), t(u[lo:hi]), t(eps[lo:hi]), ops.Workspace())
+        acc_l, acc_g = acc_l + l, acc_g + g
+        assert torch.equal(z, full[1][lo:hi])
+    assert abs(float(acc_l[0]) - float(full[0][0])) <= 1e-6 * abs(float(full[0][0]))
+    assert relmax(acc_g.cpu().numpy(), full[2].cpu().numpy()) < 1e-6
+
+
+def test_corr_kernel_matches_numpy_corrcoef(golden_dir):
+    z = np.load(golden_dir + "/mcc.npz")
+    for i in range(int(z["n_cases"])):
+        x, y = z[f"x{i}"], z[f"y{i}"]
+        cc = ivae_amd.mcc.corr_matrix_gpu(x, y).cpu().numpy()
+        assert np.abs(cc - z[f"cc{i}"]).max() < 1e-12, i      # float64 arithmetic, as numpy
+        assert abs(ivae_amd.mean_corr_coef(x, y) - float(z[f"mcc{i}"])) < 1e-12
+    with pytest.raises(ValueError):
+        ivae_amd.mean_corr_coef(z["x0"], torch.from_numpy(z["y0"]))
+
+
+def test_corr_large_n_property():
+    """Full-size property check (N = 40000 x d = 10, the final-eval shape of runners/ivae.py:123):
+    corr(x, x) has unit diagonal, corr is invariant to affine maps, symmetric under swap."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(40000, 10, generator=g).to(dev())
+    y = (x @ torch.randn(10, 10, generator=g).to(dev())).tanh()
+    cxx = ops.corr(x, x)
+    assert (cxx.diagonal() - 1).abs().max() < 1e-12
+    cxy, cyx = ops.corr(x, y), ops.corr(y, x)
+    assert (cxy - cyx.T).abs().max() < 1e-12
+    c2 = ops.corr(x * 3 + 2, y * -0.5 + 1)
+    assert (c2 + cxy).abs().max() < 1e-6       # sign flips, magnitude kept (fp32 affine map rounding)
+
+
+def test_bad_inputs_raise():
+    c = Case("ivae_plain_tiny")
+    d = dev()
+    x, u, eps = (torch.from_numpy(t).to(d) for t in c.inputs())
+    P = torch.from_numpy(flat(c.params, c.spec.param_names())).to(d)
+    bad = ops.ModelShape(3, 100, 4, 8, 3, "lrelu", .1)       # latent_dim beyond the kernels' limit
+    with pytest.raises(RuntimeError):
+        ops.elbo_fwd_bwd(bad, ops.make_coef(global_batch=5), P, x, u, eps, ops.Workspace())
+    with pytest.raises(TypeError):
+        ops.elbo_fwd_bwd(shape_of(c), ops.make_coef(global_batch=5), P, x.double(), u, eps, ops.Workspace())
+    with pytest.raises(RuntimeError):
+        ops.elbo_fwd_bwd(shape_of(c), ops.make_coef(global_batch=5), P, x.cpu(), u, eps, ops.Workspace())
