@@ -127,9 +127,10 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
  * Replaces optimizer.step() of torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8)
  *   runners/ivae.py:38,91   models/wrappers.py:44,70,127,151
  * over a flat arena of n floats.  `step` is the 1-based step count of THIS update.
- * lr is read per call (ReduceLROnPlateau mutates it, runners/ivae.py:39,113-114). */
+ * lr is read per call (ReduceLROnPlateau mutates it, runners/ivae.py:39,113-114).  Hyper-parameters
+ * are doubles, as torch holds them (1-beta2 must be formed in double to match). */
 int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float* grads,
-                   int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+                   int64_t n, double lr, double beta1, double beta2, double eps, int64_t step,
                    void* stream);
 
 /* ---- MCC correlation ------------------------------------------------------------------

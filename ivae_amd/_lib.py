@@ -49,7 +49,7 @@ def lib():
         raise RuntimeError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
                            "ivae_amd has no fallback path")
     L = C.CDLL(LIB_PATH)
-    vp, f32 = C.c_void_p, C.c_float
+    vp, f64 = C.c_void_p, C.c_double
     pd, pc = C.POINTER(IvaeDims), C.POINTER(IvaeCoef)
     L.ivae_param_count.argtypes = [pd, C.POINTER(C.c_int64)]
     L.ivae_workspace_bytes.argtypes = [pd, C.POINTER(C.c_size_t)]
@@ -58,7 +58,7 @@ def lib():
     L.ivae_forward.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_pairwise.argtypes = [C.c_int32, C.c_int32, C.c_int32, pc, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ivae_backward.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
-    L.ivae_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, f32, f32, f32, f32, C.c_int64, vp]
+    L.ivae_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, f64, f64, f64, f64, C.c_int64, vp]
     L.ivae_corr_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_size_t)]
     L.ivae_corr.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_size_t, vp]
     L.ivae_last_hip_error.restype = C.c_char_p

@@ -22,15 +22,15 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
     }
 }
 
-hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2,
-                       float eps, int64_t step, hipStream_t st) {
-    const double bc1 = 1.0 - pow((double)b1, (double)step);
-    const double bc2 = 1.0 - pow((double)b2, (double)step);
-    const float neg_step = (float)(-(double)lr / bc1);
+hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1, double b2,
+                       double eps, int64_t step, hipStream_t st) {
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    const float neg_step = (float)(-lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, p, m, v, g, n, (float)(1.0 - (double)b1), b2,
-                       (float)(1.0 - (double)b2), neg_step, bc2_sqrt, eps);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, p, m, v, g, n, (float)(1.0 - b1), (float)b2,
+                       (float)(1.0 - b2), neg_step, bc2_sqrt, (float)eps);
     return hipGetLastError();
 }

@@ -108,8 +108,8 @@ int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* p
     return ivae_backward(dims, coef, params, x, u, eps, loss_out, grads, workspace, workspace_bytes, stream);
 }
 
-int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float* grads, int64_t n, float lr,
-                   float beta1, float beta2, float eps, int64_t step, void* stream) {
+int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float* grads, int64_t n, double lr,
+                   double beta1, double beta2, double eps, int64_t step, void* stream) {
     if (!params || !exp_avg || !exp_avg_sq || !grads) return IVAE_E_NULLPTR;
     if (n <= 0 || step < 1) return IVAE_E_BADDIMS;
     hipError_t e = launch_adam(params, exp_avg, exp_avg_sq, grads, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);

@@ -10,7 +10,7 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
                            const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
                            float* cg, float* cv, hipStream_t st);
-hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2,
-                       float eps, int64_t step, hipStream_t st);
+hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1, double b2,
+                       double eps, int64_t step, hipStream_t st);
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st);
 size_t corr_ws_bytes(int64_t n, int d);
