@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Headline benchmark: iVAE train samples/sec (ELBO fwd + bwd + Adam) on MI355X.
+
+Workload (BASELINE.json configs[1]): iVAE d=10, M=40 segments x 1000 samples, 3-layer
+leaky-ReLU MLPs hidden 50, batch 64.  One GPU trains a packed set of independent models
+(seed sweep, north_star "batched-model set per GPU"); every model does the full sequential
+fwd+bwd+Adam step at batch 64 on its own shuffled synthetic dataset.  Ranks hold disjoint
+model sets and never communicate on the data path (weak scaling).
+
+    python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (oracle/torch_ref port of the same step on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+
+
+def synth_dataset(n_models, n_seg, n_per_seg, d, seed, device):
+    """Piecewise-stationary nonlinear-ICA data with the generator semantics of data/data.py:134-304
+    (gaussian sources modulated per segment by L~U(.5,3), 3-layer lrelu mixing with column-normalised
+    uniform matrices), drawn on the device: throughput does not depend on the values."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    N = n_seg * n_per_seg
+    L = torch.rand(n_models, n_seg, 1, d, generator=g, device=device) * 2.5 + 0.5
+    s = torch.randn(n_models, n_seg, n_per_seg, d, generator=g, device=device) * L
+    s = s.reshape(n_models, N, d)
+    A = torch.rand(n_models, d, d, generator=g, device=device) * 2 - 1
+    A = A / A.pow(2).sum(1, keepdim=True).sqrt()
+    x = s
+    for layer in range(3):
+        x = torch.bmm(x, A)
+        if layer < 2:
+            x = torch.where(x > 0, x, 0.1 * x)
+    lab = torch.arange(n_seg, device=device).repeat_interleave(n_per_seg)
+    u = torch.zeros(N, n_seg, device=device)
+    u[torch.arange(N, device=device), lab] = 1
+    return x.contiguous(), u.unsqueeze(0).expand(n_models, N, n_seg).contiguous(), s
+
+
+def flops_per_sample(shape):
+    """2*(Wsum_fwd + Wsum_wgrad + Wsum_dgrad), dgrad excluding the first layers
+    of logl/g/logv.  Config 2 -> 103 kFLOP."""
+    H, L = shape.hidden_dim, shape.n_layers
+    tot = 0
+    for m in shape.mlps:
+        i, o = shape.mlp_io(m)
+        dims = [i] + [H] * (L - 1) + [o]
+        w = [dims[k] * dims[k + 1] for k in range(L)]
+        wsum = sum(w)
+        dgrad = wsum - (0 if m == "f" else w[0])
+        tot += 2 * (2 * wsum + dgrad)
+    return tot
+
+
+def cpu_baseline(seconds=10.0):
+    """oracle/torch_ref.Trainer (== the reference's loop: elbo -> backward -> Adam.step) timed on the
+    host, 1 thread and all allotted threads; the better one is reported."""
+    from oracle import np_ref, torch_ref
+    spec = np_ref.Spec(data_dim=10, latent_dim=10, aux_dim=40, hidden_dim=50, n_layers=3, activation="lrelu")
+    coef = np_ref.Coef(pairwise=False)
+    g = torch.Generator().manual_seed(0)
+    N, B = 40000, 64
+    x = torch.randn(N, 10, generator=g)
+    u = torch.zeros(N, 40)
+    u[torch.arange(N), torch.arange(N) // 1000] = 1
+    avail = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    results = {}
+    for nt in sorted({1, min(avail, 16)}):
+        torch.set_num_threads(nt)
+        tr = torch_ref.Trainer(torch_ref.xavier_params(spec, 0), spec, coef, lr=1e-2)
+        perm = torch.randperm(N, generator=g)
+        for w in range(20):
+            idx = perm[w * B:(w + 1) * B]
+            tr.step(x[idx], u[idx])
+        t0, steps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < seconds / 2:
+            for _ in range(50):
+                idx = perm[(steps % 600) * B:(steps % 600 + 1) * B]
+                tr.step(x[idx], u[idx])
+                steps += 1
+        results[nt] = steps * B / (time.perf_counter() - t0)
+    best = max(results, key=results.get)
+    return {"value": round(results[best], 1), "unit": "samples/s", "cores": best, "kind": "port",
+            "sample": "cfg2 iVAE d=10 M=40 H=50 B=64 single model, oracle/torch_ref.Trainer (torch CPU elbo+backward+"
+                      "Adam), ~%.0f s per thread setting; by threads: %s" % (
+                          seconds / 2, {k: round(v) for k, v in results.items()})}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--models", type=int, default=256, help="independent models packed per GPU")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from ivae_amd import ops
+    from ivae_amd.trainer import PackedTrainer
+
+    shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
+    M, B = args.models, args.batch
+    x, u, _ = synth_dataset(M, 40, 1000, 10, seed=1 + rank, device=dev)
+    tr = PackedTrainer(shape, n_models=M, batch=B, lr=1e-2, seed=rank, device=dev)
+    tr.set_data(x, u)
+
+    for _ in range(args.warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    tr.kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(timed=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = tr.losses().mean().item()
+    assert np.isfinite(loss), "training diverged"
+
+    if rank == 0:
+        samples = args.steps * B * M * world
+        kern_s = tr.mean_kernel_seconds()
+        algo_flops = tr.dominant_flops_per_sample(flops_per_sample(shape)) * B * M
+        achieved = algo_flops / kern_s / 1e12
+        out = {
+            "metric": "iVAE train samples/sec (fwd+bwd+Adam) at d=10,M=40",
+            "value": round(samples / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: iVAE d=10, 40 segments x 1000 samples, 3-layer lrelu MLPs "
+                                   "hidden 50, batch 64, plain ELBO + Adam lr 1e-2",
+                       "models_per_gpu": M, "batch": B, "impl": tr.impl, "rng": tr.rng,
+                       "parallelism": "independent model sets per GPU, no collective"},
+            "steps_per_s_per_model": round(args.steps / dt, 1),
+            "final_mean_loss": round(loss, 3),
+            "roofline": {"bound": "mfma", "kernel": tr.dominant_kernel, "achieved": round(achieved, 4),
+                         "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 5),
+                         "traffic": None, "avg_launch_us": round(kern_s * 1e6, 2),
+                         "algorithmic_flops_per_launch": algo_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""Packed-model training loop: many independent iVAE runs (seeds / sweeps) advanced in lock-step
+on one GPU, each doing the reference's per-step sequence
+
+    zero_grad -> elbo -> backward -> Adam.step        (runners/ivae.py:69-91, wrappers.py:60-70)
+
+on its own shuffled dataset, without the per-step host syncs of the reference loops (`loss.item()`
+runners/ivae.py:84, host MCC :86): losses stay on the device until asked for.
+Data lives in HBM for the whole run; batches are formed on the device (DataLoader(shuffle=True,
+drop_last=True) semantics, runners/ivae.py:25).
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+def init_packed_params(shape, n_models, seed, device, xavier=True):
+    """Per-model parameters with the reference's initial distributions: weights xavier-uniform
+    (nets.py:10-12,432) or nn.Linear's default U(+-1/sqrt(fan_in)) when xavier=False
+    (cleanIVAE/cleanVAE/VAE), biases U(+-1/sqrt(fan_in)).  Returns (n_models, P)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    parts = []
+    H, L = shape.hidden_dim, shape.n_layers
+    for m in shape.mlps:
+        i, o = shape.mlp_io(m)
+        dims = [i] + [H] * (L - 1) + [o]
+        for k in range(L):
+            fi, fo = dims[k], dims[k + 1]
+            wb = math.sqrt(6.0 / (fi + fo)) if xavier else 1.0 / math.sqrt(fi)
+            parts.append((torch.rand(n_models, fo * fi, generator=g, device=device) * 2 - 1) * wb)
+            parts.append((torch.rand(n_models, fo, generator=g, device=device) * 2 - 1) / math.sqrt(fi))
+    return torch.cat(parts, 1).contiguous()
+
+
+class PackedTrainer:
+    """Generic-kernel implementation (any shape): one ivae_forward / ivae_backward / ivae_adam_step
+    launch sequence per step covers all models."""
+    impl = "generic kernels (k_forward, k_backward, k_reduce, k_adam)"
+    rng = "torch.randn on device"
+    dominant_kernel = "k_backward+k_reduce"
+
+    def __init__(self, shape, n_models, batch, lr=1e-2, seed=0, device="cuda", coef=None, xavier=True,
+                 dataset_size=None):
+        self.shape, self.M, self.B, self.lr = shape, n_models, batch, lr
+        self.dev = torch.device(device)
+        self.params = init_packed_params(shape, n_models, seed, self.dev, xavier)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.t = 0
+        self.gen = torch.Generator(device=self.dev).manual_seed(seed + 12345)
+        self.coef_kw = coef or dict(a=1., b=1., c=1., d=1., pairwise=False)
+        self.decoder_var = .01
+        self.ws = ops.Workspace()
+        self.kernel_ms = []
+        self._ev = []
+        self._loss = None
+        self._batches = None
+        self._cursor = 0
+        self.N = dataset_size
+
+    def set_data(self, x, u):
+        self.x, self.u = x, u
+        self.N = self.N or x.shape[1]
+        self._batches = None
+
+    def _reshuffle(self):
+        M, N, B = self.M, self.x.shape[1], self.B
+        nb = N // B                                   # drop_last=True
+        perm = torch.rand(M, N, generator=self.gen, device=self.dev).argsort(1)[:, :nb * B]
+        gx = torch.gather(self.x, 1, perm.unsqueeze(-1).expand(-1, -1, self.x.shape[2]))
+        self._bx = gx.view(M, nb, B, -1).transpose(0, 1).contiguous()          # (nb, M, B, dd)
+        if self.shape.aux_dim > 0:
+            gu = torch.gather(self.u, 1, perm.unsqueeze(-1).expand(-1, -1, self.u.shape[2]))
+            self._bu = gu.view(M, nb, B, -1).transpose(0, 1).contiguous()
+        self._batches, self._cursor = nb, 0
+
+    def step(self, timed=False):
+        if self._batches is None or self._cursor >= self._batches:
+            self._reshuffle()
+        x = self._bx[self._cursor]
+        u = self._bu[self._cursor] if self.shape.aux_dim > 0 else None
+        self._cursor += 1
+        eps = torch.randn(self.M, self.B, self.shape.latent_dim, generator=self.gen, device=self.dev)
+        coef = ops.make_coef(N=self.N, decoder_var=self.decoder_var, global_batch=self.B, **self.coef_kw)
+        if self.coef_kw.get("pairwise"):
+            loss, z, grads = ops.elbo_fwd_bwd(self.shape, coef, self.params, x, u, eps, self.ws, self.M)
+        else:
+            z = ops.forward(self.shape, coef, self.params, x, u, eps, self.ws, self.M)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            loss, grads = ops.backward(self.shape, coef, self.params, x, u, eps, self.ws, self.M)
+            if timed:
+                e1.record()
+                self._ev.append((e0, e1))
+        self.t += 1
+        ops.adam_step(self.params.view(-1), self.exp_avg.view(-1), self.exp_avg_sq.view(-1), grads.view(-1),
+                      self.lr, self.t)
+        self._loss, self._z = loss, z
+        return loss
+
+    def losses(self):
+        return self._loss
+
+    def mean_kernel_seconds(self):
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._ev]
+        return 1e-3 * sum(ms) / max(len(ms), 1)
+
+    def dominant_flops_per_sample(self, total):
+        """Share of SURVEY §8(d)'s per-sample FLOPs done by the dominant (backward) kernel:
+        wgrad + dgrad = total - forward."""
+        sh = self.shape
+        fwd = 0
+        for m in sh.mlps:
+            i, o = sh.mlp_io(m)
+            dims = [i] + [sh.hidden_dim] * (sh.n_layers - 1) + [o]
+            fwd += 2 * sum(dims[k] * dims[k + 1] for k in range(sh.n_layers))
+        return total - fwd
