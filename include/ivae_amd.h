@@ -123,6 +123,29 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
                   float* loss_out, float* grads,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused persistent training ---------------------------------------------------------
+ * n_steps consecutive iterations of   zero_grad -> elbo -> backward -> Adam.step
+ *   runners/ivae.py:75-91   models/wrappers.py:64-70   (plain ELBO: models/nets.py:475,599)
+ * for n_models independent models in ONE launch sequence: one workgroup per model keeps the
+ * parameters in LDS and the Adam moments in registers across the steps; batches are gathered by
+ * row index from datasets resident in device memory (DataLoader(shuffle=True) semantics are the
+ * caller's choice of indices, runners/ivae.py:25).  Only shapes for which
+ * ivae_train_steps_supported() returns 1 (3 layers, lrelu, batch 64, plain ELBO, LDS fit).
+ *   params/exp_avg/exp_avg_sq (n_models, P) in/out;  x_data (n_models, n_data, data_dim);
+ *   u_data (n_models, n_data, aux_dim) or NULL;  batch_idx (n_models, n_steps, 64) int32 rows;
+ *   eps (n_models, n_steps, 64, latent_dim) or NULL -> in-kernel Philox4x32-10 + Box-Muller (seed);
+ *   step0 = Adam steps already taken;  loss_out (n_models, n_steps);
+ *   z_out (n_models, 64, latent_dim) of the LAST step, or NULL.
+ * coef: a, b, d, decoder_var are used (pairwise must be 0, global_batch 64). */
+int ivae_train_steps_supported(const IvaeDims* dims);
+int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef,
+                     float* params, float* exp_avg, float* exp_avg_sq,
+                     const float* x_data, const float* u_data, int64_t n_data,
+                     const int32_t* batch_idx, const float* eps, uint64_t seed,
+                     int32_t n_steps, int64_t step0,
+                     double lr, double beta1, double beta2, double adam_eps,
+                     float* loss_out, float* z_out, void* stream);
+
 /* ---- Adam ---------------------------------------------------------------------------
  * Replaces optimizer.step() of torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8)
  *   runners/ivae.py:38,91   models/wrappers.py:44,70,127,151

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 #include "kernels.h"
+#include "fused_train.h"
 
 static thread_local char g_err[256] = "";
 
@@ -114,6 +116,45 @@ int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float
     if (n <= 0 || step < 1) return IVAE_E_BADDIMS;
     hipError_t e = launch_adam(params, exp_avg, exp_avg_sq, grads, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_adam_step");
+}
+
+int ivae_train_steps_supported(const IvaeDims* d) {
+    if (ivae_check_dims(d) != IVAE_OK) return 0;
+    return fused_supported(d->data_dim, d->latent_dim, d->aux_dim, d->hidden_dim, d->n_layers, d->activation, d->batch) ? 1 : 0;
+}
+
+int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
+                     const float* x_data, const float* u_data, int64_t n_data, const int32_t* batch_idx,
+                     const float* eps, uint64_t seed, int32_t n_steps, int64_t step0, double lr, double beta1,
+                     double beta2, double adam_eps, float* loss_out, float* z_out, void* stream) {
+    int rc = ivae_check_dims(dims);
+    if (rc) return rc;
+    if ((rc = check_coef(dims, coef))) return rc;
+    if (!ivae_train_steps_supported(dims) || coef->pairwise || coef->global_batch != dims->batch) return IVAE_E_TOOLARGE;
+    if (!params || !exp_avg || !exp_avg_sq || !x_data || !batch_idx || !loss_out || (dims->aux_dim > 0 && !u_data))
+        return IVAE_E_NULLPTR;
+    if (n_steps <= 0 || n_data <= 0 || step0 < 0) return IVAE_E_BADDIMS;
+    FusedArgs A;
+    A.params = params; A.exp_avg = exp_avg; A.exp_avg_sq = exp_avg_sq;
+    A.x_data = x_data; A.u_data = u_data; A.batch_idx = batch_idx; A.eps = eps;
+    A.loss_out = loss_out; A.n_data = n_data; A.seed = seed;
+    A.a = coef->a; A.b = coef->b; A.d = coef->d; A.decoder_var = coef->decoder_var; A.slope = dims->slope;
+    A.w1 = (float)(1.0 - beta1); A.beta2 = (float)beta2; A.w2 = (float)(1.0 - beta2); A.adam_eps = (float)adam_eps;
+    A.n_steps_total = n_steps;
+    for (int begin = 0; begin < n_steps; begin += FT_MAX_STEPS) {
+        const int n = n_steps - begin < FT_MAX_STEPS ? n_steps - begin : FT_MAX_STEPS;
+        A.n_steps = n; A.step_begin = begin; A.step0 = step0 + begin;
+        A.z_out = begin + n == n_steps ? z_out : nullptr;
+        for (int s = 0; s < n; ++s) {
+            const double t = (double)(step0 + begin + s + 1);
+            A.neg_step[s] = (float)(-lr / (1.0 - pow(beta1, t)));
+            A.inv_bc2_sqrt[s] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
+        }
+        hipError_t e = launch_train_steps(dims->data_dim, dims->latent_dim, dims->aux_dim, dims->hidden_dim, A,
+                                          dims->n_models, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ivae_train_steps");
+    }
+    return IVAE_OK;
 }
 
 int ivae_corr_workspace_bytes(int64_t n, int32_t d, size_t* out) {

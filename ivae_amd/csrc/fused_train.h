@@ -1,0 +1,31 @@
+// Arguments of the fused persistent train-step kernel (fused_train.hip).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+#define FT_MAX_STEPS 128
+
+struct FusedArgs {
+    float* params;            // (n_models, P) in/out
+    float* exp_avg;           // (n_models, P) in/out
+    float* exp_avg_sq;        // (n_models, P) in/out
+    const float* x_data;      // (n_models, n_data, data_dim)
+    const float* u_data;      // (n_models, n_data, aux_dim) or null
+    const int* batch_idx;     // (n_models, n_steps, 64)
+    const float* eps;         // (n_models, n_steps, 64, latent) or null -> Philox(seed)
+    float* loss_out;          // (n_models, n_steps)
+    float* z_out;             // (n_models, 64, latent) of the last step, or null
+    int64_t n_data;
+    unsigned long long seed;
+    int64_t step0;            // Adam steps done before this launch
+    int n_steps;              // steps in THIS launch (<= FT_MAX_STEPS)
+    int n_steps_total;        // step extent of batch_idx / eps / loss_out
+    int step_begin;           // first step of this launch inside that extent
+    float a, b, d, decoder_var, slope;
+    float w1, beta2, w2, adam_eps;      // 1-beta1, beta2, 1-beta2, eps
+    float neg_step[FT_MAX_STEPS];       // -lr / (1 - beta1^t)
+    float inv_bc2_sqrt[FT_MAX_STEPS];   // 1 / sqrt(1 - beta2^t)
+};
+
+bool fused_supported(int dd, int dl, int m, int h, int n_layers, int act, int batch);
+hipError_t launch_train_steps(int dd, int dl, int m, int h, const FusedArgs& A, int n_models, hipStream_t st);

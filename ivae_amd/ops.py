@@ -205,3 +205,40 @@ def corr(x, y):
         check(_lib.lib().ivae_corr(_ptr(x), _ptr(y), n, d, _ptr(cc), _ptr(ws), ws.numel() * 8, _stream(dev)),
               "ivae_corr")
     return cc
+
+
+def train_steps_supported(shape, batch):
+    return bool(_lib.lib().ivae_train_steps_supported(C.byref(shape.dims(batch))))
+
+
+def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_idx, step0, lr, eps=None, seed=0,
+                beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False):
+    """ivae_train_steps: n_steps fused (elbo -> backward -> Adam) iterations for all packed models.
+    params/exp_avg/exp_avg_sq (n_models, P) are updated in place; batch_idx (n_models, n_steps, B) int32.
+    Returns (loss (n_models, n_steps), z of the last step or None)."""
+    for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (x_data, "x_data")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"{n} must be a contiguous float32 ROCm tensor")
+    if batch_idx.dtype != torch.int32 or not batch_idx.is_contiguous() or batch_idx.dim() != 3:
+        raise TypeError("batch_idx must be a contiguous int32 (n_models, n_steps, batch) tensor")
+    n_models, n_steps, B = batch_idx.shape
+    if params.shape[0] != n_models or x_data.shape[0] != n_models:
+        raise ValueError("params / x_data / batch_idx disagree on n_models")
+    if shape.aux_dim > 0:
+        u_data = _f32c(u_data, "u_data")
+    else:
+        u_data = None
+    if eps is not None:
+        eps = _f32c(eps, "eps")
+        if tuple(eps.shape) != (n_models, n_steps, B, shape.latent_dim):
+            raise ValueError("eps must be (n_models, n_steps, batch, latent_dim)")
+    dims = shape.dims(B, n_models)
+    dev = params.device
+    with torch.cuda.device(dev):
+        loss = torch.empty(n_models, n_steps, dtype=torch.float32, device=dev)
+        z = torch.empty(n_models, B, shape.latent_dim, dtype=torch.float32, device=dev) if want_z else None
+        check(_lib.lib().ivae_train_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                          _ptr(x_data), _ptr(u_data), x_data.shape[1], _ptr(batch_idx), _ptr(eps),
+                                          int(seed), n_steps, int(step0), float(lr), float(beta1), float(beta2),
+                                          float(adam_eps), _ptr(loss), _ptr(z), _stream(dev)), "ivae_train_steps")
+    return loss, z
