@@ -101,10 +101,11 @@ def cpu_baseline(seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1250)
+    ap.add_argument("--warmup", type=int, default=125)
     ap.add_argument("--models", type=int, default=256, help="independent models packed per GPU")
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--impl", choices=["fused", "generic"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,23 +119,31 @@ def main():
     torch.cuda.set_device(dev)
 
     from ivae_amd import ops
-    from ivae_amd.trainer import PackedTrainer
+    from ivae_amd.trainer import FusedPackedTrainer, PackedTrainer
 
     shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
     M, B = args.models, args.batch
     x, u, _ = synth_dataset(M, 40, 1000, 10, seed=1 + rank, device=dev)
-    tr = PackedTrainer(shape, n_models=M, batch=B, lr=1e-2, seed=rank, device=dev)
+    fused = args.impl == "fused"
+    if fused:
+        tr = FusedPackedTrainer(shape, n_models=M, batch=B, lr=1e-2, seed=rank, device=dev)
+    else:
+        tr = PackedTrainer(shape, n_models=M, batch=B, lr=1e-2, seed=rank, device=dev)
     tr.set_data(x, u)
 
-    for _ in range(args.warmup):
-        tr.step()
+    def advance(n, timed):
+        if fused:
+            tr.run(n, timed=timed)
+        else:
+            for _ in range(n):
+                tr.step(timed=timed)
+
+    advance(args.warmup, False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    tr.kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step(timed=True)
+    advance(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -148,13 +157,18 @@ def main():
 
     if rank == 0:
         samples = args.steps * B * M * world
-        kern_s = tr.mean_kernel_seconds()
-        algo_flops = tr.dominant_flops_per_sample(flops_per_sample(shape)) * B * M
+        fps = flops_per_sample(shape)
+        if fused:
+            kern_s, steps_per_launch = tr.mean_kernel_seconds()
+            algo_flops = fps * B * M * steps_per_launch
+        else:
+            kern_s, steps_per_launch = tr.mean_kernel_seconds(), 1
+            algo_flops = tr.dominant_flops_per_sample(fps) * B * M
         achieved = algo_flops / kern_s / 1e12
         out = {
             "metric": "iVAE train samples/sec (fwd+bwd+Adam) at d=10,M=40",
             "value": round(samples / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: iVAE d=10, 40 segments x 1000 samples, 3-layer lrelu MLPs "
                                    "hidden 50, batch 64, plain ELBO + Adam lr 1e-2",
@@ -165,7 +179,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": tr.dominant_kernel, "achieved": round(achieved, 4),
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 5),
                          "traffic": None, "avg_launch_us": round(kern_s * 1e6, 2),
-                         "algorithmic_flops_per_launch": algo_flops},
+                         "steps_per_launch": steps_per_launch, "algorithmic_flops_per_launch": algo_flops},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -118,3 +118,77 @@ class PackedTrainer:
             dims = [i] + [sh.hidden_dim] * (sh.n_layers - 1) + [o]
             fwd += 2 * sum(dims[k] * dims[k + 1] for k in range(sh.n_layers))
         return total - fwd
+
+
+class FusedPackedTrainer:
+    """Fused-kernel implementation: `ivae_train_steps` advances every packed model by up to 128
+    steps per launch (parameters in LDS, Adam moments in registers, in-kernel Philox noise).
+    Host work per launch: one slice of the epoch's device-side permutation."""
+    impl = "fused persistent kernel (k_train_steps)"
+    rng = "in-kernel Philox4x32-10 + Box-Muller"
+    dominant_kernel = "k_train_steps"
+    CHUNK = 125          # steps per launch (divides the 625-step epoch of N=40000, B=64)
+
+    def __init__(self, shape, n_models, batch, lr=1e-2, seed=0, device="cuda", xavier=True, decoder_var=.01,
+                 a=1., b=1., d=1.):
+        if not ops.train_steps_supported(shape, batch):
+            raise RuntimeError("shape not covered by the fused kernel; use PackedTrainer")
+        self.shape, self.M, self.B, self.lr, self.seed = shape, n_models, batch, lr, seed
+        self.dev = torch.device(device)
+        self.params = init_packed_params(shape, n_models, seed, self.dev, xavier)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.t = 0
+        self.gen = torch.Generator(device=self.dev).manual_seed(seed + 12345)
+        self.coef = ops.make_coef(a=a, b=b, d=d, decoder_var=decoder_var, global_batch=batch)
+        self._ev, self._launch_steps = [], []
+        self._perm, self._cursor, self._nb = None, 0, 0
+        self._loss = None
+
+    def set_data(self, x, u):
+        self.x = x.contiguous()
+        self.u = u.contiguous() if u is not None else None
+        self._perm = None
+
+    def _reshuffle(self):
+        N = self.x.shape[1]
+        self._nb = N // self.B                                      # drop_last=True (runners/ivae.py:25)
+        self._perm = torch.rand(self.M, N, generator=self.gen, device=self.dev).argsort(1).to(torch.int32)
+        self._cursor = 0
+
+    def run(self, n_steps, timed=False, want_z=False):
+        """Advance all models by n_steps; returns the (n_models, n_steps) loss tensor (device)."""
+        out, z = [], None
+        while n_steps > 0:
+            if self._perm is None or self._cursor >= self._nb:
+                self._reshuffle()
+            k = min(n_steps, self.CHUNK, self._nb - self._cursor)
+            idx = self._perm[:, self._cursor * self.B:(self._cursor + k) * self.B].reshape(self.M, k, self.B).contiguous()
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            loss, z = ops.train_steps(self.shape, self.coef, self.params, self.exp_avg, self.exp_avg_sq, self.x, self.u,
+                                      idx, self.t, self.lr, seed=self.seed, want_z=want_z and k == n_steps)
+            if timed:
+                e1.record()
+                self._ev.append((e0, e1))
+                self._launch_steps.append(k)
+            out.append(loss)
+            self.t += k
+            self._cursor += k
+            n_steps -= k
+        self._loss = out[-1][:, -1]
+        self._z = z
+        return torch.cat(out, 1) if len(out) > 1 else out[0]
+
+    def step(self, timed=False):
+        return self.run(1, timed)
+
+    def losses(self):
+        return self._loss
+
+    def mean_kernel_seconds(self):
+        """Average duration of one k_train_steps launch and the steps it covered."""
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._ev]
+        return 1e-3 * sum(ms) / max(len(ms), 1), sum(self._launch_steps) / max(len(self._launch_steps), 1)
