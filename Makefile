@@ -16,6 +16,11 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
+# diagnostic build with in-kernel phase stamps (never shipped, never benchmarked)
+prof: ivae_amd/libivae_amd_prof.so
+ivae_amd/libivae_amd_prof.so: $(SRCS) $(HDRS)
+	$(HIPCC) $(CXXFLAGS) -DFT_PROF -shared $(SRCS) -o $@
+
 clean:
 	rm -f $(OBJS) $(LIB)
 

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libivae_amd.so")
+# IVAE_AMD_LIB selects another build of the same ABI (the `make prof` diagnostic library)
+LIB_PATH = os.environ.get("IVAE_AMD_LIB") or os.path.join(_HERE, "libivae_amd.so")
 
 ACT_IDS = {"none": 0, "lrelu": 1, "xtanh": 2, "sigmoid": 3}
 

@@ -29,6 +29,23 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (make prof): s_memtime stamps at phase boundaries of model 0 / wave 0 go to a
+// buffer of their own; no output depends on them and the shipped library contains none.
+#ifdef FT_PROF
+__device__ unsigned long long* g_ft_prof = nullptr;
+#define FT_NSTAMP 64
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && g_ft_prof) {                                    \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            g_ft_prof[(size_t)s * FT_NSTAMP + (i)] = t_;                                           \
+        }                                                                                          \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 #define FT_THREADS 256
 #define FT_B 64
 #define LOG2PI_F 1.8378770664093453f
@@ -67,7 +84,7 @@ struct FCfg {
     static constexpr int ARENA_PAD = (NPARAM + 3) & ~3;
     static constexpr int TILE = FT_B * SA;
     static constexpr int SMALL = FT_B * SS;
-    static constexpr int LDS_FLOATS = ARENA_PAD + 5 * TILE + 4 * SMALL + 64;   // +64: slack for tile over-reads
+    static constexpr int LDS_FLOATS = ARENA_PAD + 5 * TILE + 4 * SMALL + 96;   // +96: column sums, loss partials, slack for tile over-reads
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
     static_assert(H <= 64 && KIN <= 64 && DD <= 16 && DL <= 16, "tile plan assumes <=64 wide hidden/input, <=16 wide heads");
     static_assert(LDS_BYTES <= 160 * 1024, "does not fit the 160 KB LDS");
@@ -80,6 +97,13 @@ __device__ __forceinline__ int opaque_lane() {
     int l = threadIdx.x & 63;
     asm volatile("" : "+v"(l));
     return l;
+}
+
+// Workgroup barrier that waits only for this wave's LDS traffic.  All cross-wave hand-offs inside the
+// step loop go through LDS; __syncthreads() would also drain vmcnt and so expose the latency of the
+// next batch's prefetch (global loads into registers that nothing reads until the next step).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -220,26 +244,34 @@ __device__ __forceinline__ void wgrad_block(const float* dY, int sy, int N, cons
         }
 }
 
-// Adam for one layer: gradient from the staging tile (weights) / column sums of dY (bias).
+// Column sums of a (64, >=64-wide or narrow) delta tile = the bias gradient of its layer.  Wave w owns
+// columns 16w..16w+15; lane = (row group of 16 rows) x (column); two xor-shuffles finish the sum.
+__device__ __forceinline__ void colsum64(const float* dY, int sy, int ncols, float* cs, int w) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, rg = lane >> 4;
+    if (16 * w < ncols) {
+        const float* p = dY + (rg * 16) * sy + 16 * w + c;
+        float sum = 0.f;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) sum += p[b * sy];
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        if (rg == 0) cs[16 * w + c] = sum;
+    }
+}
+
+// Adam for one layer: gradient from the staging tile (weights) / the column sums `cs` (bias).
 // Same update as k_adam (adam.hip) / torch.optim.Adam; sqrt and the final divide use the hardware
 // v_sqrt_f32 / v_rcp_f32 (1 ulp) -- a <=2e-7 relative change of a step of size ~lr.
 template <int P, int NK, int CNT, int REG0, int NA>
-__device__ __forceinline__ void adam_layer(float* arena_layer, const float* stage, const float* dY, int sy,
+__device__ __forceinline__ void adam_layer(float* arena_layer, const float* stage, const float* cs,
                                            float (&am)[NA], float (&av)[NA], float w1, float b2, float w2,
                                            float neg_step, float inv_bc2, float eps) {
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
         const int idx = threadIdx.x + j * FT_THREADS;
         if (idx < P) {
-            float g;
-            if (idx < NK) {
-                g = stage[idx];
-            } else {
-                const int n = idx - NK;
-                g = 0.f;
-#pragma unroll 4
-                for (int b = 0; b < FT_B; ++b) g += dY[b * sy + n];
-            }
+            const float g = idx < NK ? stage[idx] : cs[idx - NK];
             const float m0 = am[REG0 + j], v0 = av[REG0 + j];
             const float mi = m0 + w1 * (g - m0);
             const float vi = v0 * b2 + (w2 * g) * g;
@@ -289,11 +321,44 @@ __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned
     const float u1 = ((float)(c1 >> 8) + 0.5f) * (1.f / 16777216.f);
     const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.f / 16777216.f);
     const float u3 = ((float)(c3 >> 8) + 0.5f) * (1.f / 16777216.f);
-    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
-    float s0, c0f, s1, c1f;
-    sincosf(6.283185307179586f * u1, &s0, &c0f);
-    sincosf(6.283185307179586f * u3, &s1, &c1f);
+    // Box-Muller on the hardware transcendental units: v_log_f32 (log2), v_sin/v_cos (argument in turns)
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+    const float s0 = __builtin_amdgcn_sinf(u1), c0f = __builtin_amdgcn_cosf(u1);
+    const float s1 = __builtin_amdgcn_sinf(u3), c1f = __builtin_amdgcn_cosf(u3);
     out[0] = r0 * c0f; out[1] = r0 * s0; out[2] = r1 * c1f; out[3] = r1 * s1;
+}
+
+// Gather one batch [x | u] (zero-padded to SA columns) into registers, element e = tid + j*256, in two
+// stages so that neither load latency is exposed: the row indices of the slots (issued one phase
+// earlier), then the elements (branch-free: out-of-range slots read a dummy address and are zeroed).
+template <class C>
+__device__ __forceinline__ void load_rows(int (&rows)[cdiv(FT_B * C::SA, FT_THREADS)], const int* idx) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));      // keep the per-thread (row, column) decode out of the step loop's live set
+#pragma unroll
+    for (int j = 0; j < cdiv(FT_B * C::SA, FT_THREADS); ++j) {
+        const int b = (t + j * FT_THREADS) / C::SA;
+        rows[j] = idx[b < FT_B ? b : FT_B - 1];
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void load_xu(float (&xu)[cdiv(FT_B * C::SA, FT_THREADS)],
+                                        const int (&rows)[cdiv(FT_B * C::SA, FT_THREADS)], const float* xd,
+                                        const float* ud) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int j = 0; j < cdiv(FT_B * C::SA, FT_THREADS); ++j) {
+        const int e = t + j * FT_THREADS;
+        const int b = e / C::SA, k = e - b * C::SA;
+        const bool valid = b < FT_B && k < C::KIN;
+        const size_t row = (size_t)rows[j];
+        const float* p = k < C::DD ? xd + row * C::DD + k : ud + row * C::M + (k - C::DD);
+        const float val = *(valid ? p : xd);
+        xu[j] = valid ? val : 0.f;
+    }
 }
 
 // ---------------------------------------------------------------------------------- kernel
@@ -314,7 +379,8 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
     float* sV = sG + C::SMALL;
     float* sL = sV + C::SMALL;
     float* sZ = sL + C::SMALL;
-    float* red = sZ + C::SMALL;          // 64 floats of slack double as the loss-reduction scratch
+    float* csum = sZ + C::SMALL;         // 64 column sums (bias gradients); the slack also absorbs tile over-reads
+    float* red = csum + 64;              // 4 loss partials
 
     constexpr int SA = C::SA, SS = C::SS, H = C::H, DD = C::DD, DL = C::DL, M = C::M, KIN = C::KIN;
     const int tid = threadIdx.x;
@@ -351,6 +417,11 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
     __syncthreads();
 
     const float w1 = A.w1, b2 = A.beta2, w2 = A.w2, aeps = A.adam_eps;
+    constexpr int NXU = cdiv(FT_B * C::SA, FT_THREADS);
+    float xu[NXU];
+    int rows[NXU];
+    load_rows<C>(rows, idxp);
+    load_xu<C>(xu, rows, xd, ud);
 
     for (int s = 0; s < A.n_steps; ++s) {
         // block coordinates (wave-uniform), re-derived per step behind an optimisation barrier so the
@@ -363,26 +434,31 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
         const float neg_step = A.neg_step[s], inv_bc2 = A.inv_bc2_sqrt[s];
         const int* idx = idxp + (size_t)s * FT_B;
 
-        // ---- P0: gather the batch: XU = [x | u] -> A4 (pad columns zero)
-        for (int e = tid; e < FT_B * SA; e += FT_THREADS) {
-            const int b = e / SA, k = e - b * SA;
-            float val = 0.f;
-            if (k < KIN) {
-                const size_t row = (size_t)idx[b];
-                val = k < DD ? xd[row * DD + k] : ud[row * M + (k - DD)];
+        STAMP(0);
+        // ---- P0: the batch [x | u] was prefetched into registers during the previous step -> A4; eps -> sZ
+#pragma unroll
+        for (int j = 0; j < NXU; ++j) { const int e = tid + j * FT_THREADS; if (e < FT_B * SA) A4[e] = xu[j]; }
+        if (A.eps) {
+            for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
+                const int b = e / SS, k = e - b * SS;
+                if (k < DL) sZ[e] = A.eps[(((size_t)model * A.n_steps_total + A.step_begin + s) * FT_B + b) * DL + k];
             }
-            A4[e] = val;
+        } else if (tid * 4 < FT_B * DL) {
+            float nrm[4];
+            philox_normal4(A.seed, (unsigned)tid, (unsigned)(A.step0 + s), (unsigned)model, 0x1234567u, nrm);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int el = tid * 4 + i; sZ[(el / DL) * SS + el % DL] = nrm[i]; }
         }
-        __syncthreads();
+        lds_barrier(); STAMP(1);
 
         // ---- encoder g / logv layers 1-2; outputs stashed in registers for the backward pass
         f32x4 st1g[2][2], st1v[2][2], st2g[2][2], st2v[2][2], st3[2][2], st4[2][2];
         fwd_block<2, 2, 0>(A4, SA, arena + C::OFF_G0, KIN, arena + C::OFF_G0 + H * KIN, H, A0, SA, r22, c22, slope, st1g);
         fwd_block<2, 2, 0>(A4, SA, arena + C::OFF_V0, KIN, arena + C::OFF_V0 + H * KIN, H, A1, SA, r22, c22, slope, st1v);
-        __syncthreads();
+        lds_barrier(); STAMP(2);
         fwd_block<2, 2, 0>(A0, SA, arena + C::OFF_G1, H, arena + C::OFF_G1 + H * H, H, A2, SA, r22, c22, slope, st2g);
         fwd_block<2, 2, 0>(A1, SA, arena + C::OFF_V1, H, arena + C::OFF_V1 + H * H, H, A3, SA, r22, c22, slope, st2v);
-        __syncthreads();
+        lds_barrier(); STAMP(3);
         // ---- heads g -> sG, v = exp(logv) -> sV (row tile rt); prior layer 1 shares the phase (A0 is free)
         {
             f32x4 acc[1][1];
@@ -391,28 +467,20 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
         }
         if (C::HAS_U) {
             fwd_block<2, 2, 0>(A4 + DD, SA, arena + C::OFF_L0, M, arena + C::OFF_L0 + H * M, H, A0, SA, r22, c22, slope, st3);
-            __syncthreads();
+            lds_barrier(); STAMP(4);
             fwd_block<2, 2, 0>(A0, SA, arena + C::OFF_L1, H, arena + C::OFF_L1 + H * H, H, A1, SA, r22, c22, slope, st4);
-            __syncthreads();
+            lds_barrier(); STAMP(5);
             f32x4 acc[1][1];
             fwd_block<1, 1, 2>(A1, SA, arena + C::OFF_L2, H, arena + C::OFF_L2 + DL * H, DL, sL, SS, rt, 0, slope, acc);
         }
-        __syncthreads();
+        lds_barrier(); STAMP(6);
         // ---- Z: reparameterisation + latent log-densities (nets.py:301-314)
         float lsum = 0.f;
         for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
             const int b = e / SS, k = e - b * SS;
             float zz = 0.f;
             if (k < DL) {
-                float ep;
-                if (A.eps) {
-                    ep = A.eps[(((size_t)model * A.n_steps_total + A.step_begin + s) * FT_B + b) * DL + k];
-                } else {
-                    float nrm[4];
-                    const unsigned el = (unsigned)(b * DL + k);
-                    philox_normal4(A.seed, el >> 2, (unsigned)(A.step0 + s), (unsigned)model, 0x1234567u, nrm);
-                    ep = nrm[el & 3];
-                }
+                const float ep = sZ[e];
                 const float gg = sG[e], vv = sV[e];
                 const float ll = C::HAS_U ? sL[e] : 1.f;
                 zz = ep * sqrtf(vv) + gg;
@@ -425,14 +493,14 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
             }
             sZ[e] = zz;
         }
-        __syncthreads();
+        lds_barrier(); STAMP(7);
         // ---- decoder f: z -> h1f (A0) -> h2f (A1) -> f; dOut = dLoss/df -> A2, log p(x|z)
         {
             f32x4 acc[2][2];
             fwd_block<2, 2, 0>(sZ, SS, arena + C::OFF_F0, DL, arena + C::OFF_F0 + H * DL, H, A0, SA, r22, c22, slope, acc);
-            __syncthreads();
+            lds_barrier(); STAMP(8);
             fwd_block<2, 2, 0>(A0, SA, arena + C::OFF_F1, H, arena + C::OFF_F1 + H * H, H, A1, SA, r22, c22, slope, acc);
-            __syncthreads();
+            lds_barrier(); STAMP(9);
         }
         {
             // A2 becomes the zero-padded dOut tile: columns >= 16 zeroed by everyone, the head tile written below
@@ -462,31 +530,34 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0) red[w] = v;
         }
-        __syncthreads();
+        lds_barrier(); STAMP(10);
         if (tid == 0) {
             const float t = (red[0] + red[1]) + (red[2] + red[3]);
             A.loss_out[(size_t)model * A.n_steps_total + A.step_begin + s] = -t * wB;
         }
 
 #define ADAM(P_, NK_, CNT_, REG_, OFF_, DY_, SY_) \
-        adam_layer<P_, NK_, CNT_, REG_>(arena + OFF_, A4, DY_, SY_, am, av, w1, b2, w2, neg_step, inv_bc2, aeps)
+        adam_layer<P_, NK_, CNT_, REG_>(arena + OFF_, A4, csum, am, av, w1, b2, w2, neg_step, inv_bc2, aeps)
 
         // ---- decoder backward.  layer 3: d2f -> A3
         dgrad_block<2, 2, 1>(A2, SA, DD, arena + C::OFF_F2, H, A1, SA, A3, SA, r22, c22, slope);
         wgrad_block<1, 1>(A2, SA, DD, A1, SA, H, A4, 0, rt);
-        __syncthreads();
+        colsum64(A2, SA, DD, csum, w);
+        lds_barrier(); STAMP(11);
         ADAM(C::P_F2, DD * H, C::C_F2, C::R_F2, C::OFF_F2, A2, SA);
-        __syncthreads();
+        lds_barrier(); STAMP(12);
         // layer 2: d1f -> A1
         dgrad_block<2, 2, 1>(A3, SA, H, arena + C::OFF_F1, H, A0, SA, A1, SA, r22, c22, slope);
         wgrad_block<2, 2>(A3, SA, H, A0, SA, H, A4, r22, c22);
-        __syncthreads();
+        colsum64(A3, SA, H, csum, w);
+        lds_barrier(); STAMP(13);
         ADAM(C::P_F1, H * H, C::C_F1, C::R_F1, C::OFF_F1, A3, SA);
-        __syncthreads();
+        lds_barrier(); STAMP(14);
         // layer 1: dz -> A2 (16 columns)
         dgrad_block<1, 1, 0>(A1, SA, H, arena + C::OFF_F0, DL, nullptr, 0, A2, SA, rt, 0, slope);
         wgrad_block<1, 1>(A1, SA, H, sZ, SS, DL, A4, rt, 0);
-        __syncthreads();
+        colsum64(A1, SA, H, csum, w);
+        lds_barrier(); STAMP(15);
         ADAM(C::P_F0, H * DL, C::C_F0, C::R_F0, C::OFF_F0, A1, SA);
         // ---- E: head deltas in place (SURVEY §8 a-bwd): sG <- dg, sV <- dlogv, sL <- dlogl
         for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
@@ -507,73 +578,78 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
         // bias sums of the decoder's first layer above, A2 (dz) by the delta loop.
         restore_block<2, 2>(st2g, A0, SA, r22, c22);
         restore_block<2, 2>(st1g, A3, SA, r22, c22);
-        __syncthreads();
+        lds_barrier(); STAMP(16);
 
         // ---- g backward: d2g -> A2, d1g -> A1
+        if (s + 1 < A.n_steps) load_rows<C>(rows, idx + FT_B);     // next batch's row indices, used one phase later
         dgrad_block<2, 2, 1>(sG, SS, DL, arena + C::OFF_G2, H, A0, SA, A2, SA, r22, c22, slope);
         wgrad_block<1, 1>(sG, SS, DL, A0, SA, H, A4, 0, rt);
-        __syncthreads();
+        colsum64(sG, SS, DL, csum, w);
+        lds_barrier(); STAMP(17);
         ADAM(C::P_E2, DL * H, C::C_E2, C::R_G2, C::OFF_G2, sG, SS);
-        __syncthreads();
+        lds_barrier(); STAMP(18);
         dgrad_block<2, 2, 1>(A2, SA, H, arena + C::OFF_G1, H, A3, SA, A1, SA, r22, c22, slope);
         wgrad_block<2, 2>(A2, SA, H, A3, SA, H, A4, r22, c22);
-        // reload XU into A0 (h2g is dead) for the first-layer weight gradients of g / logv / logl
-        for (int e = tid; e < FT_B * SA; e += FT_THREADS) {
-            const int b = e / SA, k = e - b * SA;
-            float val = 0.f;
-            if (k < KIN) {
-                const size_t row = (size_t)idx[b];
-                val = k < DD ? xd[row * DD + k] : ud[row * M + (k - DD)];
-            }
-            A0[e] = val;
-        }
-        __syncthreads();
+        // XU again (registers -> A0, h2g is dead) for the first-layer weight gradients of g / logv / logl,
+        // then start fetching the next step's batch: its latency hides behind the rest of this step
+#pragma unroll
+        for (int j = 0; j < NXU; ++j) { const int e = tid + j * FT_THREADS; if (e < FT_B * SA) A0[e] = xu[j]; }
+        if (s + 1 < A.n_steps) load_xu<C>(xu, rows, xd, ud);
+        colsum64(A2, SA, H, csum, w);
+        lds_barrier(); STAMP(19);
         ADAM(C::P_E1, H * H, C::C_E1, C::R_G1, C::OFF_G1, A2, SA);
-        __syncthreads();
+        lds_barrier(); STAMP(20);
         wgrad_block<2, 2>(A1, SA, H, A0, SA, KIN, A4, r22, c22);
-        __syncthreads();
+        colsum64(A1, SA, H, csum, w);
+        lds_barrier(); STAMP(21);
         ADAM(C::P_E0, H * KIN, C::C_E0, C::R_G0, C::OFF_G0, A1, SA);
         // restore logv's hidden activations: h2v -> A2 (d2g dead), h1v -> A3 (h1g dead); A1 busy (bias sums)
         restore_block<2, 2>(st2v, A2, SA, r22, c22);
         restore_block<2, 2>(st1v, A3, SA, r22, c22);
-        __syncthreads();
+        lds_barrier(); STAMP(22);
 
         // ---- logv backward: d2v -> A1, d1v -> A2
         dgrad_block<2, 2, 1>(sV, SS, DL, arena + C::OFF_V2, H, A2, SA, A1, SA, r22, c22, slope);
         wgrad_block<1, 1>(sV, SS, DL, A2, SA, H, A4, 0, rt);
-        __syncthreads();
+        colsum64(sV, SS, DL, csum, w);
+        lds_barrier(); STAMP(23);
         ADAM(C::P_E2, DL * H, C::C_E2, C::R_V2, C::OFF_V2, sV, SS);
-        __syncthreads();
+        lds_barrier(); STAMP(24);
         dgrad_block<2, 2, 1>(A1, SA, H, arena + C::OFF_V1, H, A3, SA, A2, SA, r22, c22, slope);
         wgrad_block<2, 2>(A1, SA, H, A3, SA, H, A4, r22, c22);
-        __syncthreads();
+        colsum64(A1, SA, H, csum, w);
+        lds_barrier(); STAMP(25);
         ADAM(C::P_E1, H * H, C::C_E1, C::R_V1, C::OFF_V1, A1, SA);
-        __syncthreads();
+        lds_barrier(); STAMP(26);
         wgrad_block<2, 2>(A2, SA, H, A0, SA, KIN, A4, r22, c22);
-        __syncthreads();
+        colsum64(A2, SA, H, csum, w);
+        lds_barrier(); STAMP(27);
         ADAM(C::P_E0, H * KIN, C::C_E0, C::R_V0, C::OFF_V0, A2, SA);
 
         // ---- logl backward: h2l -> A1 (d2v dead), h1l -> A3 (h1v dead); d2l -> A2 (after the sync), d1l -> A1
         if (C::HAS_U) {
             restore_block<2, 2>(st4, A1, SA, r22, c22);
             restore_block<2, 2>(st3, A3, SA, r22, c22);
-            __syncthreads();
+            lds_barrier(); STAMP(28);
             dgrad_block<2, 2, 1>(sL, SS, DL, arena + C::OFF_L2, H, A1, SA, A2, SA, r22, c22, slope);
             wgrad_block<1, 1>(sL, SS, DL, A1, SA, H, A4, 0, rt);
-            __syncthreads();
+            colsum64(sL, SS, DL, csum, w);
+            lds_barrier(); STAMP(29);
             ADAM(C::P_L2, DL * H, C::C_L2, C::R_L2, C::OFF_L2, sL, SS);
-            __syncthreads();
+            lds_barrier(); STAMP(30);
             dgrad_block<2, 2, 1>(A2, SA, H, arena + C::OFF_L1, H, A3, SA, A1, SA, r22, c22, slope);
             wgrad_block<2, 2>(A2, SA, H, A3, SA, H, A4, r22, c22);
-            __syncthreads();
+            colsum64(A2, SA, H, csum, w);
+            lds_barrier(); STAMP(31);
             ADAM(C::P_L1, H * H, C::C_L1, C::R_L1, C::OFF_L1, A2, SA);
-            __syncthreads();
+            lds_barrier(); STAMP(32);
             wgrad_block<2, 2>(A1, SA, H, A0 + DD, SA, M, A4, r22, c22);
-            __syncthreads();
+            colsum64(A1, SA, H, csum, w);
+            lds_barrier(); STAMP(33);
             ADAM(C::P_L0, H * M, C::C_L0, C::R_L0, C::OFF_L0, A1, SA);
         }
 #undef ADAM
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- write state back
@@ -609,6 +685,12 @@ static hipError_t launch_cfg(const FusedArgs& A, int n_models, hipStream_t st) {
 }
 
 #define FT_SHAPES(X) X(10, 10, 40, 50) X(10, 10, 0, 50) X(5, 5, 40, 50) X(5, 5, 0, 50)
+
+#ifdef FT_PROF
+extern "C" int ivae_debug_set_prof(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ft_prof), &buf, sizeof(buf));
+}
+#endif
 
 bool fused_supported(int dd, int dl, int m, int h, int n_layers, int act, int batch) {
     if (n_layers != 3 || act != IVAE_ACT_LRELU || batch != FT_B) return false;
