@@ -1,0 +1,42 @@
+"""Host data generator (ivae_amd/data.py) vs the reference generator's outputs recorded in
+tests/golden/datasets.json (tools/make_golden.py datasets): same legacy np.random stream, same bytes.
+Bit-exactness holds on the numpy/BLAS build the fixture was made with (this image); elsewhere the
+leading values and sums are compared at fp32 tolerance."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ivae_amd import data as D
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "datasets.json")))
+
+
+@pytest.mark.parametrize("i", range(len(GOLD)))
+def test_generator_matches_reference(i):
+    rec = GOLD[i]
+    S, X, U, M, L = D.generate_data(batch_size=0, repeat_linearity=True, **rec["kwargs"])
+    exact = True
+    for k, a in (("s", S), ("x", X), ("u", U), ("m", M), ("L", L)):
+        a = np.ascontiguousarray(a)
+        assert list(a.shape) == rec[k]["shape"] and str(a.dtype) == rec[k]["dtype"], k
+        np.testing.assert_allclose(a.reshape(-1)[:6], rec[k]["head"], rtol=1e-5, atol=1e-6)
+        assert abs(float(a.astype(np.float64).sum()) - rec[k]["sum"]) <= 1e-4 * max(1.0, abs(rec[k]["sum"])), k
+        exact &= hashlib.sha256(a.tobytes()).hexdigest() == rec[k]["sha256"]
+    assert exact, "generator output is numerically close to the reference but not bit-identical"
+
+
+def test_dataset_cache_name_and_keys(tmp_path):
+    root = str(tmp_path) + "/"
+    ds = D.SyntheticDataset(root, 20, 3, 2, 2, 3, 1, 'gauss', 'xtanh')
+    assert os.path.exists(root + "tcl_20_3_2_2_3_1_gauss_xtanh.npz")
+    z = np.load(root + "tcl_20_3_2_2_3_1_gauss_xtanh.npz")
+    assert sorted(z.files) == ["L", "m", "s", "u", "x"]
+    assert ds.get_dims() == (2, 2, 3) and len(ds) == 60
+    x, u, s = ds[5]
+    assert x.shape == (2,) and u.shape == (3,) and float(u.sum()) == 1.0
+    assert D.dataset_path("r/", 1, 2, 3, 4, 5, 6, 'lap', 'lrelu', True, True) == "r/tcl_1_2_3_4_5_6_lap_lrelu_u_noisy.npz"
+    cd = D.CustomSyntheticDataset(ds.x.numpy(), ds.u.numpy(), ds.s.numpy())
+    assert cd.get_metadata()["nps"] == 20

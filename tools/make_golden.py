@@ -171,8 +171,87 @@ def make_mcc():
     print("mcc fixtures", [float(out[f"mcc{i}"]) for i in range(len(cases))])
 
 
+DATASET_CASES = [
+    dict(n_per_seg=50, n_seg=6, d_sources=3, d_data=3, n_layers=3, seed=1, prior='gauss', activation='xtanh'),
+    dict(n_per_seg=40, n_seg=5, d_sources=4, d_data=4, n_layers=3, seed=7, prior='gauss', activation='lrelu'),
+    dict(n_per_seg=30, n_seg=4, d_sources=2, d_data=4, n_layers=2, seed=3, prior='lap', activation='sigmoid'),
+    dict(n_per_seg=30, n_seg=4, d_sources=3, d_data=3, n_layers=4, seed=5, prior='hs', activation='none',
+         uncentered=True, noisy=0.1),
+    dict(n_per_seg=1000, n_seg=40, d_sources=5, d_data=5, n_layers=3, seed=1, prior='gauss', activation='xtanh'),   # configs/ivae.yaml
+    dict(n_per_seg=1000, n_seg=40, d_sources=10, d_data=10, n_layers=3, seed=1, prior='gauss', activation='lrelu'),  # BASELINE cfg 2
+]
+
+
+def make_datasets():
+    """sha256 + leading values of the reference generator's outputs (data/data.py:200-304, called as
+    load_tcl_data does: repeat_linearity=True, batch_size=0).  np.int was removed from numpy 2: the reference
+    needs the in-process alias below to run at all."""
+    import hashlib
+    if not hasattr(np, "int"):
+        np.int = int
+    from data.data import generate_data
+    out = []
+    for kw in DATASET_CASES:
+        S, X, U, M, L = generate_data(batch_size=0, repeat_linearity=True, **kw)
+        rec = dict(kwargs=kw)
+        for k, a in (("s", S), ("x", X), ("u", U), ("m", M), ("L", L)):
+            a = np.ascontiguousarray(a)
+            rec[k] = dict(sha256=hashlib.sha256(a.tobytes()).hexdigest(), dtype=str(a.dtype), shape=list(a.shape),
+                          head=[float(v) for v in a.reshape(-1)[:6]], sum=float(a.astype(np.float64).sum()))
+        out.append(rec)
+        print("dataset", kw["n_per_seg"], kw["n_seg"], kw["d_sources"], rec["x"]["sha256"][:12])
+    json.dump(out, open(os.path.join(OUT, "datasets.json"), "w"), indent=1)
+
+
+def trace_batches(seed, epoch, N, B):
+    """Batch order used by the trace fixtures (DataLoader(shuffle=True, drop_last=True) semantics)."""
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(100 * seed + epoch))
+    return perm[:(N // B) * B].view(-1, B)
+
+
+def make_traces(n_seeds=4, epochs=2, B=64):
+    """Reference iVAE (BASELINE config 2) trained on CPU for `epochs` epochs with a recorded batch order
+    and per-step noise seeds -> per-step loss trace and final MCC, for the end-to-end parity test
+    (tests/test_gpu_e2e.py replays the same batches and eps through the fused kernel)."""
+    if not hasattr(np, "int"):
+        np.int = int
+    from data.data import generate_data
+    S, X, U, _, _ = generate_data(1000, 40, 10, 10, n_layers=3, seed=1, prior='gauss', activation='lrelu',
+                                  batch_size=0, repeat_linearity=True)
+    Xt, Ut = torch.from_numpy(X), torch.from_numpy(U)
+    N = X.shape[0]
+    out = dict(n_seeds=np.array(n_seeds), epochs=np.array(epochs), batch=np.array(B))
+    for seed in range(n_seeds):
+        torch.manual_seed(seed)
+        model = iVAE(10, 10, 40, n_layers=3, hidden_dim=50, activation='lrelu', slope=.1)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        losses, step = [], 0
+        for epoch in range(epochs):
+            for idx in trace_batches(seed, epoch, N, B):
+                torch.manual_seed(1_000_000 * (seed + 1) + step)      # the elbo's randn(B, d) draw
+                opt.zero_grad()
+                elbo, z = model.elbo(Xt[idx], Ut[idx])
+                elbo.mul(-1).backward()
+                opt.step()
+                losses.append(-elbo.item())
+                step += 1
+        with torch.no_grad():
+            torch.manual_seed(777 + seed)
+            (_, _), (g, v), z, _ = model(Xt, Ut)
+        out[f"loss{seed}"] = np.array(losses, np.float32)
+        out[f"mcc_sample{seed}"] = np.array(mean_corr_coef_np(S, z.numpy()))
+        out[f"mcc_mean{seed}"] = np.array(mean_corr_coef_np(S, g.numpy()))
+        print(f"trace seed {seed}: loss {losses[0]:.2f} -> {np.mean(losses[-50:]):.3f}  mcc(sample) "
+              f"{float(out[f'mcc_sample{seed}']):.4f} mcc(mean) {float(out[f'mcc_mean{seed}']):.4f}")
+    np.savez_compressed(os.path.join(OUT, "trace_cfg2.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "datasets":
+        return make_datasets()
+    if len(sys.argv) > 1 and sys.argv[1] == "traces":
+        return make_traces()
     # family B (models/nets.py:391-486, 548-599)
     make_case("ivae_plain_tiny", "iVAE", (3, 3, 4), B=5, H=8)
     make_case("ivae_plain_cfg2", "iVAE", (10, 10, 40), B=64, H=50)
