@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def case_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
-                  if not p.endswith("mcc.npz"))
+                  if not os.path.basename(p).startswith(("mcc", "trace_")))
 
 
 class Case:
