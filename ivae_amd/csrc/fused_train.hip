@@ -1,5 +1,5 @@
-// Fused persistent train-step kernel: one 256-thread workgroup (4 waves, one per SIMD) trains one model for n_steps
-// consecutive SGD steps without leaving the CU.
+// Fused persistent train-step kernel: one 512-thread workgroup (8 waves, two per SIMD) trains one
+// model for n_steps consecutive SGD steps without leaving the CU.
 //
 //   per step:  gather batch rows by index -> encoder/prior/decoder forward (fp32 MFMA) ->
 //              reparameterisation + Gaussian log-densities + loss -> analytic backward
@@ -9,24 +9,27 @@
 // models/nets.py:450-475 (iVAE) or 587-599 (VAE) and torch.optim.Adam.
 //
 // On-chip residency:
-//   * parameter arena: LDS, exactly the torch `parameters()` layout (weights (out,in) row-major,
-//     then bias), so a weight row stride is its in-dim (50, 10: = 2 mod 4 -> conflict-free
-//     operand reads);
+//   * parameters: LDS, one (N, KS) matrix per nn.Linear with the bias folded in as column K (the
+//     activation tiles carry a constant-1 column there), rows padded to KS = 4*odd floats so that
+//     64-bit operand reads are bank-conflict free;
 //   * Adam exp_avg / exp_avg_sq: registers, flat per-layer ownership (thread t owns elements
-//     t, t+256, ... of each layer), loaded once per launch, written back once;
-//   * activations: five (64, SA) LDS tiles + four (64, SS) row tensors; hidden activations the
-//     backward pass needs later are stashed in the producing wave's registers (MFMA C layout)
-//     and written back to LDS when their MLP's backward starts: no recompute, no HBM round trip;
-//   * weight gradients of one layer at a time are staged in an LDS tile and consumed by Adam
-//     right away: no gradient arena exists.
-// Every layer product (fwd, dgrad, wgrad) is v_mfma_f32_16x16x4_f32 (exact fp32 fma chain) on
-// 16x16 tiles with operands read from LDS; contraction dims are zero-padded to a multiple of 4,
-// output tiles past the real dims are discarded in the epilogues.
+//     t, t+512, ... of each layer), loaded once per launch, written back once;
+//   * activations: five (64, ST) LDS tiles + four (64, SS) row tensors; hidden activations the
+//     backward pass needs later are stashed in the producing wave's registers (MFMA C layout) and
+//     written back to LDS one phase before their MLP's backward needs them;
+//   * the weight gradient of a layer is staged in a dead tile and consumed by Adam one phase later
+//     (while the next layer's products run on the matrix pipe): no gradient arena exists.
+// Every layer product (fwd, dgrad, wgrad) is v_mfma_f32_16x16x4_f32 (exact fp32 fma chain).  A wave
+// owns a PAIR of 16x16 output tiles whose columns interleave (tile j holds columns col0+2c+j), so
+// operands and results move as 64-bit LDS accesses; the contraction index is permuted the same
+// way on both operands (lane q takes k = 8t+2q, 8t+2q+1), which leaves every sum unchanged up to
+// fp32 summation order.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "kernels.h"
 #include "fused_train.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Diagnostic build only (make prof): s_memtime stamps at phase boundaries of model 0 / wave 0 go to a
@@ -46,47 +49,53 @@ __device__ unsigned long long* g_ft_prof = nullptr;
 #define STAMP(i)
 #endif
 
-#define FT_THREADS 256
+#define FT_THREADS 512
 #define FT_B 64
 #define LOG2PI_F 1.8378770664093453f
 
-__host__ __device__ constexpr int pad4(int x) { return (x + 3) & ~3; }
 __host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+__host__ __device__ constexpr int cmin(int a, int b) { return a < b ? a : b; }
+// smallest 4*odd >= x: a row stride s with s/2 = 2*odd puts the 32 lanes of one ds_read_b64 group
+// (16 rows x 2 column pairs) on 32 distinct bank pairs
+__host__ __device__ constexpr int odd4(int x) { return (((x + 3) >> 2) | 1) << 2; }
 
 // ---------------------------------------------------------------------------------- config
+// Layer ids: 0..2 logl (absent when M == 0), 3..5 f, 6..8 g, 9..11 logv  (torch parameters() order).
+enum { L_L0 = 0, L_L1, L_L2, L_F0, L_F1, L_F2, L_G0, L_G1, L_G2, L_V0, L_V1, L_V2, N_LAYERS };
+
 template <int DD_, int DL_, int M_, int H_>
 struct FCfg {
-    static constexpr int DD = DD_, DL = DL_, M = M_, H = H_, KIN = DD_ + M_;
+    static constexpr int DD = DD_, DL = DL_, M = M_, H = H_;
     static constexpr bool HAS_U = M_ > 0;
-    // arena (torch order): [logl] f g logv ; per MLP: W1 b1 W2 b2 W3 b3
-    static constexpr int P_L0 = HAS_U ? H * M + H : 0, P_L1 = HAS_U ? H * H + H : 0, P_L2 = HAS_U ? DL * H + DL : 0;
-    static constexpr int P_F0 = H * DL + H, P_F1 = H * H + H, P_F2 = DD * H + DD;
-    static constexpr int P_E0 = H * KIN + H, P_E1 = H * H + H, P_E2 = DL * H + DL;
-    static constexpr int OFF_L0 = 0, OFF_L1 = OFF_L0 + P_L0, OFF_L2 = OFF_L1 + P_L1;
-    static constexpr int OFF_F0 = OFF_L2 + P_L2, OFF_F1 = OFF_F0 + P_F0, OFF_F2 = OFF_F1 + P_F1;
-    static constexpr int OFF_G0 = OFF_F2 + P_F2, OFF_G1 = OFF_G0 + P_E0, OFF_G2 = OFF_G1 + P_E1;
-    static constexpr int OFF_V0 = OFF_G2 + P_E2, OFF_V1 = OFF_V0 + P_E0, OFF_V2 = OFF_V1 + P_E1;
-    static constexpr int NPARAM = OFF_V2 + P_E2;
-    // Adam register slots per layer (flat ownership: thread t owns t, t+256, ...)
-    static constexpr int C_L0 = cdiv(P_L0, FT_THREADS), C_L1 = cdiv(P_L1, FT_THREADS), C_L2 = cdiv(P_L2, FT_THREADS);
-    static constexpr int C_F0 = cdiv(P_F0, FT_THREADS), C_F1 = cdiv(P_F1, FT_THREADS), C_F2 = cdiv(P_F2, FT_THREADS);
-    static constexpr int C_E0 = cdiv(P_E0, FT_THREADS), C_E1 = cdiv(P_E1, FT_THREADS), C_E2 = cdiv(P_E2, FT_THREADS);
-    static constexpr int R_L0 = 0, R_L1 = R_L0 + C_L0, R_L2 = R_L1 + C_L1;
-    static constexpr int R_F0 = R_L2 + C_L2, R_F1 = R_F0 + C_F0, R_F2 = R_F1 + C_F1;
-    static constexpr int R_G0 = R_F2 + C_F2, R_G1 = R_G0 + C_E0, R_G2 = R_G1 + C_E1;
-    static constexpr int R_V0 = R_G2 + C_E2, R_V1 = R_V0 + C_E0, R_V2 = R_V1 + C_E1;
-    static constexpr int NADAM = R_V2 + C_E2;
-    // LDS activation tiles
-    static constexpr int WMAX = cmax(cmax(H, KIN), cmax(DD, DL));
-    static constexpr int SA = pad4(WMAX) + 2;                 // = 2 (mod 4): conflict-free row-strided reads
-    static constexpr int SS = pad4(DL) + 2;
-    static constexpr int ARENA_PAD = (NPARAM + 3) & ~3;
-    static constexpr int TILE = FT_B * SA;
-    static constexpr int SMALL = FT_B * SS;
-    static constexpr int LDS_FLOATS = ARENA_PAD + 5 * TILE + 4 * SMALL + 96;   // +96: column sums, loss partials, slack for tile over-reads
+    static constexpr int UOFF = HAS_U ? ((DD_ + 1) & ~1) : 0;       // first column of u in the [x | u] tile (even)
+    static constexpr int KIN = HAS_U ? UOFF + M_ : DD_;             // its constant-1 (bias) column
+    static constexpr int KS_E0 = odd4(KIN + 1), KS_H = odd4(H_ + 1), KS_L0 = odd4(M_ + 1), KS_F0 = odd4(DL_ + 1);
+    static constexpr int ST = cmax(KS_E0, KS_H);                    // activation tile row stride
+    static constexpr int SS = odd4(cmax(DL_, DD_) + 1);             // row-tensor stride
+    // per layer: output rows N, LDS row stride KS, bias column KB, torch in-features KR
+    static constexpr int n_of(int l) { return (l < 3 && !HAS_U) ? 0 : (l == L_L2 || l == L_G2 || l == L_V2) ? DL : (l == L_F2 ? DD : H); }
+    static constexpr int ks_of(int l) { return l == L_L0 ? KS_L0 : l == L_F0 ? KS_F0 : (l == L_G0 || l == L_V0) ? KS_E0 : KS_H; }
+    static constexpr int kb_of(int l) { return l == L_L0 ? M : l == L_F0 ? DL : (l == L_G0 || l == L_V0) ? KIN : H; }
+    static constexpr int kr_of(int l) { return l == L_L0 ? M : l == L_F0 ? DL : (l == L_G0 || l == L_V0) ? DD + M : H; }
+    static constexpr int off_of(int l) { int o = 0; for (int i = 0; i < l; ++i) o += n_of(i) * ks_of(i); return o; }      // LDS
+    static constexpr int goff_of(int l) { int o = 0; for (int i = 0; i < l; ++i) o += n_of(i) * (kr_of(i) + 1); return o; } // torch arena
+    static constexpr int NPARAM = goff_of(N_LAYERS);
+    static constexpr int ARENA = (off_of(N_LAYERS) + 3) & ~3;
+    // Adam register slots: thread t owns elements t, t+512, ... of the (N, KB+1) index space of a layer
+    static constexpr int p_of(int l) { return n_of(l) * (kb_of(l) + 1); }
+    static constexpr int cnt_of(int l) { return cdiv(p_of(l), FT_THREADS); }
+    static constexpr int reg_of(int l) { int o = 0; for (int i = 0; i < l; ++i) o += cnt_of(i); return o; }
+    static constexpr int NADAM = reg_of(N_LAYERS);
+    static constexpr int TILE = FT_B * ST, SMALL = FT_B * SS;
+    static constexpr int STG_F2 = H * KS_H;                         // offset of the decoder-head gradient stage inside its tile
+    static constexpr int LDS_FLOATS = ARENA + 5 * TILE + 4 * SMALL + 64;   // +64: slack for tile over-reads past the last row
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
-    static_assert(H <= 64 && KIN <= 64 && DD <= 16 && DL <= 16, "tile plan assumes <=64 wide hidden/input, <=16 wide heads");
+    static constexpr int NXU = cdiv(ST, 8);                         // prefetch registers: thread = (row, 1/8 of the columns)
+    static_assert(ST <= 64 && H_ <= 62, "tile-pair plan covers at most 64 columns");
+    static_assert(DD_ <= 15 && DL_ <= 15, "heads are one 16-wide tile");
+    static_assert(STG_F2 + DD_ * KS_H <= TILE && SMALL + H_ * KS_F0 + 16 <= TILE, "stage aliasing plan");
+    static_assert(DL_ * KS_H <= SMALL, "head-gradient stage aliases the z row tensor");
     static_assert(LDS_BYTES <= 160 * 1024, "does not fit the 160 KB LDS");
 };
 
@@ -109,196 +118,308 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-
-// acc[m][n] += A(rows i) x B(cols j) over ksteps*4; operands in LDS.
-// A element (i,k) at A[i*a_si + k*a_sk], B element (k,j) at Bp[j*b_sj + k*b_sk]; pointers already at
-// the block origin.  Lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15].
-template <int BM, int BN>
-__device__ __forceinline__ void mma_block(const float* A, int a_si, int a_sk, const float* Bp, int b_sj, int b_sk,
-                                          int ksteps, f32x4 (&acc)[BM][BN]) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, q = lane >> 4;
-    const float* ap = A + c * a_si + q * a_sk;
-    const float* bp = Bp + c * b_sj + q * b_sk;
-#pragma unroll 2
-    for (int s = 0; s < ksteps; ++s) {
-        float a[BM], b[BN];
-#pragma unroll
-        for (int m = 0; m < BM; ++m) a[m] = ap[m * 16 * a_si];
-#pragma unroll
-        for (int n = 0; n < BN; ++n) b[n] = bp[n * 16 * b_sj];
-#pragma unroll
-        for (int m = 0; m < BM; ++m)
-#pragma unroll
-            for (int n = 0; n < BN; ++n) acc[m][n] = mfma4(a[m], b[n], acc[m][n]);
-        ap += 4 * a_sk;
-        bp += 4 * b_sk;
-    }
-}
-
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = (f32x2){a, b}; }
 __device__ __forceinline__ float lrelu(float p, float slope) { return p > 0.f ? p : p * slope; }
 
-// Forward layer block: Y[b][n] = epi(bias[n] + sum_k X[b][k] W[n][k]); C rows = b, cols = n.
-// EPI 0: lrelu -> out (stride so), columns >= N written as 0 (keeps contraction padding zero)
-// EPI 1: identity -> out      EPI 2: exp -> out
-template <int BM, int BN, int EPI>
-__device__ __forceinline__ void fwd_block(const float* X, int sx, const float* W, int K, const float* bias, int N,
-                                          float* out, int so, int row0, int col0, float slope, f32x4 (&acc)[BM][BN]) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, q = lane >> 4;
+#define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
+
+// ---- products.  c = lane & 15, q = lane >> 4.  MFMA operand slots: A[i = c][k = q], B[k = q][j = c];
+// result: C[i = 4q + r][j = c], r = 0..3.
+
+// acc[w][j] += X[row][k] * W_w[n_j][k], k in [0, KS), KS = 8G + 4.  xrow = X + row*sx, wrow[w][j] = W_w + n_j*KS.
+template <int NW, int KS>
+__device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&wrow)[NW][2], int q, f32x4 (&acc)[NW][2]) {
+    constexpr int G = (KS - 4) / 8;
+    static_assert(KS == 8 * G + 4, "row strides are 4*odd");
+    f32x2 a[2], b[2][NW][2];
+    if (G > 0) {
+        a[0] = ld2(xrow + 2 * q);
 #pragma unroll
-    for (int n = 0; n < BN; ++n) {
-        const int col = col0 + n * 16 + c;
-        const float bv = col < N ? bias[col] : 0.f;
-#pragma unroll
-        for (int m = 0; m < BM; ++m) acc[m][n] = (f32x4){bv, bv, bv, bv};
+        for (int w = 0; w < NW; ++w) { b[0][w][0] = ld2(wrow[w][0] + 2 * q); b[0][w][1] = ld2(wrow[w][1] + 2 * q); }
     }
-    mma_block<BM, BN>(X + row0 * sx, sx, 1, W + col0 * K, K, 1, pad4(K) / 4, acc);
 #pragma unroll
-    for (int m = 0; m < BM; ++m)
+    for (int t = 0; t < G; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (t + 1 < G) {
+            a[nxt] = ld2(xrow + 8 * (t + 1) + 2 * q);
 #pragma unroll
-        for (int n = 0; n < BN; ++n) {
-            const int col = col0 + n * 16 + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + m * 16 + 4 * q + r;
-                float val = acc[m][n][r];
-                if (EPI == 0) val = lrelu(val, slope);
-                else if (EPI == 2) val = expf(val);
-                if (col >= N) val = 0.f;
-                acc[m][n][r] = val;
-                if (col < so) out[row * so + col] = val;
+            for (int w = 0; w < NW; ++w) {
+                b[nxt][w][0] = ld2(wrow[w][0] + 8 * (t + 1) + 2 * q);
+                b[nxt][w][1] = ld2(wrow[w][1] + 8 * (t + 1) + 2 * q);
             }
         }
-}
-
-// Write a stashed block (post-epilogue values kept in registers) back to an LDS tile.
-template <int BM, int BN>
-__device__ __forceinline__ void restore_block(const f32x4 (&st)[BM][BN], float* out, int so, int row0, int col0) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int m = 0; m < BM; ++m)
+        for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(a[cur].x, b[cur][w][0].x, acc[w][0]); acc[w][1] = mfma4(a[cur].x, b[cur][w][1].x, acc[w][1]); }
 #pragma unroll
-        for (int n = 0; n < BN; ++n) {
-            const int col = col0 + n * 16 + c;
+        for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(a[cur].y, b[cur][w][0].y, acc[w][0]); acc[w][1] = mfma4(a[cur].y, b[cur][w][1].y, acc[w][1]); }
+    }
+    const float at = xrow[8 * G + q];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (col < so) out[(row0 + m * 16 + 4 * q + r) * so + col] = st[m][n][r];
-        }
-}
-
-// dgrad block: dX[b][k] = mask(h[b][k]) * sum_n dY[b][n] W[n][k]; C rows = b, cols = k.
-// MASK 0: none (input of the MLP), 1: lrelu mask from post-activation tile `hm` (stride sh).
-template <int BM, int BN, int MASK>
-__device__ __forceinline__ void dgrad_block(const float* dY, int sy, int N, const float* W, int K, const float* hm,
-                                            int sh, float* out, int so, int row0, int col0, float slope) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, q = lane >> 4;
-    f32x4 acc[BM][BN];
-#pragma unroll
-    for (int m = 0; m < BM; ++m)
-#pragma unroll
-        for (int n = 0; n < BN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // A(i=b, k=n) = dY[b][n]; B(k=n, j=k) = W[n][k]
-    mma_block<BM, BN>(dY + row0 * sy, sy, 1, W + col0, 1, K, pad4(N) / 4, acc);
-#pragma unroll
-    for (int m = 0; m < BM; ++m)
-#pragma unroll
-        for (int n = 0; n < BN; ++n) {
-            const int col = col0 + n * 16 + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + m * 16 + 4 * q + r;
-                float val = acc[m][n][r];
-                if (col >= K) val = 0.f;
-                else if (MASK == 1) val *= (hm[row * sh + col] > 0.f ? 1.f : slope);
-                if (col < so) out[row * so + col] = val;
-            }
-        }
-}
-
-// wgrad block: dW[n][k] = sum_b dY[b][n] X[b][k]; C rows = n, cols = k; written to staging [n*K + k].
-template <int BM, int BN>
-__device__ __forceinline__ void wgrad_block(const float* dY, int sy, int N, const float* X, int sx, int K,
-                                            float* stage, int row0, int col0) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, q = lane >> 4;
-    f32x4 acc[BM][BN];
-#pragma unroll
-    for (int m = 0; m < BM; ++m)
-#pragma unroll
-        for (int n = 0; n < BN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // A(i=n, k=b) = dY[b][n]; B(k=b, j=k) = X[b][k]
-    mma_block<BM, BN>(dY + row0, 1, sy, X + col0, 1, sx, FT_B / 4, acc);
-#pragma unroll
-    for (int m = 0; m < BM; ++m)
-#pragma unroll
-        for (int n = 0; n < BN; ++n) {
-            const int col = col0 + n * 16 + c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + m * 16 + 4 * q + r;
-                if (row < N && col < K) stage[row * K + col] = acc[m][n][r];
-            }
-        }
-}
-
-// Column sums of a (64, >=64-wide or narrow) delta tile = the bias gradient of its layer.  Wave w owns
-// columns 16w..16w+15; lane = (row group of 16 rows) x (column); two xor-shuffles finish the sum.
-__device__ __forceinline__ void colsum64(const float* dY, int sy, int ncols, float* cs, int w) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, rg = lane >> 4;
-    if (16 * w < ncols) {
-        const float* p = dY + (rg * 16) * sy + 16 * w + c;
-        float sum = 0.f;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) sum += p[b * sy];
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        if (rg == 0) cs[16 * w + c] = sum;
+    for (int w = 0; w < NW; ++w) {
+        acc[w][0] = mfma4(at, wrow[w][0][8 * G + q], acc[w][0]);
+        acc[w][1] = mfma4(at, wrow[w][1][8 * G + q], acc[w][1]);
     }
 }
 
-// Adam for one layer: gradient from the staging tile (weights) / the column sums `cs` (bias).
+// single 16-wide tile: acc += X[row][k] * W[n][k]; two accumulators break the dependent chain
+template <int KS>
+__device__ __forceinline__ f32x4 mm_fwd1(const float* xrow, const float* wrow, int q) {
+    constexpr int G = (KS - 4) / 8;
+    f32x4 e = ZERO4, o = ZERO4;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const f32x2 a = ld2(xrow + 8 * t + 2 * q), b = ld2(wrow + 8 * t + 2 * q);
+        e = mfma4(a.x, b.x, e);
+        o = mfma4(a.y, b.y, o);
+    }
+    e = mfma4(xrow[8 * G + q], wrow[8 * G + q], e);
+    return e + o;
+}
+
+// acc[j] += dY[row][n] * W[n][col0 + j], n in [0, NS), NS = 8G + 4; rows n >= N (zero columns of dY) are
+// clamped to a real row.  yrow = dY + row*sy, wcol = W + col0.
+template <int NS, int N, int KS>
+__device__ __forceinline__ void mm_dgrad(const float* yrow, const float* wcol, int q, f32x4 (&acc)[2]) {
+    constexpr int G = (NS - 4) / 8;
+    static_assert(NS == 8 * G + 4, "contraction lengths are 4*odd");
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const f32x2 a = ld2(yrow + 8 * t + 2 * q);
+        int n0 = 8 * t + 2 * q, n1 = n0 + 1;
+        if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
+        const f32x2 b0 = ld2(wcol + n0 * KS), b1 = ld2(wcol + n1 * KS);
+        acc[0] = mfma4(a.x, b0.x, acc[0]);
+        acc[1] = mfma4(a.x, b0.y, acc[1]);
+        acc[0] = mfma4(a.y, b1.x, acc[0]);
+        acc[1] = mfma4(a.y, b1.y, acc[1]);
+    }
+    const float a = yrow[8 * G + q];
+    int n = 8 * G + q;
+    if (8 * G + 3 >= N) n = min(n, N - 1);
+    const f32x2 b = ld2(wcol + n * KS);
+    acc[0] = mfma4(a, b.x, acc[0]);
+    acc[1] = mfma4(a, b.y, acc[1]);
+}
+
+// single tile, scalar column: acc += dY[row][n] * W[n][col]
+template <int NS, int N, int KS>
+__device__ __forceinline__ f32x4 mm_dgrad1(const float* yrow, const float* wcol, int q) {
+    constexpr int G = (NS - 4) / 8;
+    f32x4 e = ZERO4, o = ZERO4;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const f32x2 a = ld2(yrow + 8 * t + 2 * q);
+        int n0 = 8 * t + 2 * q, n1 = n0 + 1;
+        if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
+        e = mfma4(a.x, wcol[n0 * KS], e);
+        o = mfma4(a.y, wcol[n1 * KS], o);
+    }
+    int n = 8 * G + q;
+    if (8 * G + 3 >= N) n = min(n, N - 1);
+    e = mfma4(yrow[8 * G + q], wcol[n * KS], e);
+    return e + o;
+}
+
+// acc[j] += dY[b][n] * X[b][col0 + j], b in [0, 64).  ycol = dY + n, xcol = X + col0.
+__device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float* xcol, int sx, int q, f32x4 (&acc)[2]) {
+#pragma unroll
+    for (int t = 0; t < FT_B / 4; ++t) {
+        const float a = ycol[(4 * t + q) * sy];
+        const f32x2 b = ld2(xcol + (4 * t + q) * sx);
+        acc[0] = mfma4(a, b.x, acc[0]);
+        acc[1] = mfma4(a, b.y, acc[1]);
+    }
+}
+
+__device__ __forceinline__ f32x4 mm_wgrad1(const float* ycol, int sy, const float* xcol, int sx, int q) {
+    f32x4 e = ZERO4, o = ZERO4;
+#pragma unroll
+    for (int t = 0; t < FT_B / 4; t += 2) {
+        e = mfma4(ycol[(4 * t + q) * sy], xcol[(4 * t + q) * sx], e);
+        o = mfma4(ycol[(4 * t + 4 + q) * sy], xcol[(4 * t + 4 + q) * sx], o);
+    }
+    return e + o;
+}
+
+// ---- layer blocks.  Wave w owns rows 16*(w&3).. and the column half 32*(w>>2) + 2c + j of 64-wide outputs.
+
+// Hidden layer(s) forward for NW weight matrices that share the input tile:
+// out_w[b][n] = lrelu(sum_k X[b][k] W_w[n][k]) for n < H, 1 at n == H (bias column of the next layer), 0 beyond.
+template <class C, int NW, int KS>
+__device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* const (&W)[NW], float* const (&out)[NW],
+                                           float slope, int w, f32x4 (&keep)[NW][2]) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    const float* wrow[NW][2];
+#pragma unroll
+    for (int m = 0; m < NW; ++m) {
+        wrow[m][0] = W[m] + min(col0, C::H - 1) * KS;
+        wrow[m][1] = W[m] + min(col0 + 1, C::H - 1) * KS;
+        keep[m][0] = ZERO4;
+        keep[m][1] = ZERO4;
+    }
+    mm_fwd<NW, KS>(X + (16 * rt + c) * sx, wrow, q, keep);
+    const bool in0 = col0 < C::H, in1 = col0 + 1 < C::H;
+    const float f0 = col0 == C::H ? 1.f : 0.f, f1 = col0 + 1 == C::H ? 1.f : 0.f;
+#pragma unroll
+    for (int m = 0; m < NW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v0 = in0 ? lrelu(keep[m][0][r], slope) : f0;
+            const float v1 = in1 ? lrelu(keep[m][1][r], slope) : f1;
+            keep[m][0][r] = v0;
+            keep[m][1][r] = v1;
+            if (col0 < C::ST) st2(out[m] + (16 * rt + 4 * q + r) * C::ST + col0, v0, v1);
+        }
+}
+
+// Write a stashed hidden activation (post-epilogue values kept in registers) back to an LDS tile.
+template <class C>
+__device__ __forceinline__ void restore_tile(const f32x4 (&keep)[2], float* out, int w) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (col0 < C::ST) st2(out + (16 * rt + 4 * q + r) * C::ST + col0, keep[0][r], keep[1][r]);
+}
+
+// Head forward (one 16-wide tile per 16 rows; 4 waves): out[b][n] = epi(sum_k X[b][k] W[n][k]), n < N.  EXP: exp().
+template <class C, int N, bool EXP>
+__device__ __forceinline__ void fwd_head(const float* X, const float* W, float* out, int rt) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const f32x4 acc = mm_fwd1<C::KS_H>(X + (16 * rt + c) * C::ST, W + min(c, N - 1) * C::KS_H, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (c < N) out[(16 * rt + 4 * q + r) * C::SS + c] = EXP ? expf(acc[r]) : acc[r];
+}
+
+// Hidden-layer dgrad: out[b][k] = mask(h[b][k]) * sum_n dY[b][n] W[n][k] for k < KB, 0 beyond.
+template <class C, int NS, int N, int KS, int KB>
+__device__ __forceinline__ void dgrad_hidden(const float* dY, int sy, const float* W, const float* hm, float* out,
+                                             float slope, int w) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    f32x4 acc[2] = {ZERO4, ZERO4};
+    mm_dgrad<NS, N, KS>(dY + (16 * rt + c) * sy, W + min(col0, KS - 2), q, acc);
+    const bool in0 = col0 < KB, in1 = col0 + 1 < KB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * rt + 4 * q + r;
+        if (col0 < C::ST) {
+            const f32x2 h = ld2(hm + row * C::ST + col0);
+            const float v0 = in0 ? acc[0][r] * (h.x > 0.f ? 1.f : slope) : 0.f;
+            const float v1 = in1 ? acc[1][r] * (h.y > 0.f ? 1.f : slope) : 0.f;
+            st2(out + row * C::ST + col0, v0, v1);
+        }
+    }
+}
+
+// Weight gradient of a layer with > 16 input columns: stage[n][k] = sum_b dY[b][n] X[b][k] for k <= KB (k == KB
+// is the bias gradient: X carries a constant-1 column there), 0 beyond.  Wave w: rows 16*(w&3).., column half w>>2.
+template <class C, int N, int KS, int KB>
+__device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float* X, int sx, float* stage, int w) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const int nt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    f32x4 acc[2] = {ZERO4, ZERO4};
+    mm_wgrad(dY + min(16 * nt + c, sy - 1), sy, X + min(col0, KS - 2), sx, q, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 16 * nt + 4 * q + r;
+        if (n < N && col0 < KS) st2(stage + n * KS + col0, col0 <= KB ? acc[0][r] : 0.f, col0 + 1 <= KB ? acc[1][r] : 0.f);
+    }
+}
+
+// Single-tile weight gradient: rows 16*nt.., columns 16*kt + c.
+template <class C, int N, int KS, int KB>
+__device__ __forceinline__ void wgrad_tile(const float* dY, int sy, const float* X, int sx, float* stage, int nt, int kt) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const int col = 16 * kt + c;
+    const f32x4 acc = mm_wgrad1(dY + min(16 * nt + c, sy - 1), sy, X + min(col, KS - 1), sx, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 16 * nt + 4 * q + r;
+        if (n < N && col < KS) stage[n * KS + col] = col <= KB ? acc[r] : 0.f;
+    }
+}
+
+// Adam for layer L: gradient from `stage` (same (N, KS) layout as the layer in the arena).
 // Same update as k_adam (adam.hip) / torch.optim.Adam; sqrt and the final divide use the hardware
 // v_sqrt_f32 / v_rcp_f32 (1 ulp) -- a <=2e-7 relative change of a step of size ~lr.
-template <int P, int NK, int CNT, int REG0, int NA>
-__device__ __forceinline__ void adam_layer(float* arena_layer, const float* stage, const float* cs,
-                                           float (&am)[NA], float (&av)[NA], float w1, float b2, float w2,
-                                           float neg_step, float inv_bc2, float eps) {
+template <class C, int L, int NA>
+__device__ __forceinline__ void adam_layer(float* arena, const float* stage, float (&am)[NA], float (&av)[NA], float w1,
+                                           float b2, float w2, float neg_step, float inv_bc2, float eps) {
+    constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L);
+    float* base = arena + C::off_of(L);
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
 #pragma unroll
-    for (int j = 0; j < CNT; ++j) {
-        const int idx = threadIdx.x + j * FT_THREADS;
+    for (int j = 0; j < C::cnt_of(L); ++j) {
+        const int idx = t + j * FT_THREADS;
         if (idx < P) {
-            const float g = idx < NK ? stage[idx] : cs[idx - NK];
-            const float m0 = am[REG0 + j], v0 = av[REG0 + j];
+            const int n = idx / KC;
+            const int off = n * KS + (idx - n * KC);
+            const float g = stage[off];
+            const float m0 = am[R0 + j], v0 = av[R0 + j];
             const float mi = m0 + w1 * (g - m0);
             const float vi = v0 * b2 + (w2 * g) * g;
             const float denom = __builtin_amdgcn_sqrtf(vi) * inv_bc2 + eps;
-            arena_layer[idx] = arena_layer[idx] + (neg_step * mi) * __builtin_amdgcn_rcpf(denom);
-            am[REG0 + j] = mi;
-            av[REG0 + j] = vi;
+            base[off] = base[off] + (neg_step * mi) * __builtin_amdgcn_rcpf(denom);
+            am[R0 + j] = mi;
+            av[R0 + j] = vi;
         }
     }
 }
 
-template <int P, int CNT, int REG0, int NA>
-__device__ __forceinline__ void adam_load(const float* gm, const float* gv, float (&am)[NA], float (&av)[NA]) {
+// torch arena index of element (n, k) of layer L's (N, KB+1) index space, or -1 for the hole column that
+// keeps u on an even column of the encoder input when data_dim is odd.
+template <class C, int L>
+__device__ __forceinline__ int torch_index(int n, int k) {
+    constexpr int KB = C::kb_of(L), KR = C::kr_of(L), G0 = C::goff_of(L), N = C::n_of(L);
+    if (k == KB) return G0 + N * KR + n;                      // bias
+    if ((L == L_G0 || L == L_V0) && C::HAS_U && C::UOFF != C::DD) {
+        if (k >= C::DD && k < C::UOFF) return -1;
+        if (k >= C::UOFF) k -= C::UOFF - C::DD;
+    }
+    return G0 + n * KR + k;
+}
+
+template <class C, int L, int NA>
+__device__ __forceinline__ void state_load(const float* gP, const float* gM, const float* gV, float* arena,
+                                           float (&am)[NA], float (&av)[NA]) {
+    constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L);
 #pragma unroll
-    for (int j = 0; j < CNT; ++j) {
+    for (int j = 0; j < C::cnt_of(L); ++j) {
         const int idx = threadIdx.x + j * FT_THREADS;
-        am[REG0 + j] = idx < P ? gm[idx] : 0.f;
-        av[REG0 + j] = idx < P ? gv[idx] : 0.f;
+        float m = 0.f, v = 0.f;
+        if (idx < P) {
+            const int n = idx / KC, k = idx - n * KC;
+            const int gi = torch_index<C, L>(n, k);
+            if (gi >= 0) { arena[C::off_of(L) + n * KS + k] = gP[gi]; m = gM[gi]; v = gV[gi]; }
+        }
+        am[R0 + j] = m;
+        av[R0 + j] = v;
     }
 }
 
-template <int P, int CNT, int REG0, int NA>
-__device__ __forceinline__ void adam_store(float* gm, float* gv, const float (&am)[NA], const float (&av)[NA]) {
+template <class C, int L, int NA>
+__device__ __forceinline__ void state_store(float* gP, float* gM, float* gV, const float* arena, const float (&am)[NA],
+                                            const float (&av)[NA]) {
+    constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L);
 #pragma unroll
-    for (int j = 0; j < CNT; ++j) {
+    for (int j = 0; j < C::cnt_of(L); ++j) {
         const int idx = threadIdx.x + j * FT_THREADS;
-        if (idx < P) { gm[idx] = am[REG0 + j]; gv[idx] = av[REG0 + j]; }
+        if (idx < P) {
+            const int n = idx / KC, k = idx - n * KC;
+            const int gi = torch_index<C, L>(n, k);
+            if (gi >= 0) { gP[gi] = arena[C::off_of(L) + n * KS + k]; gM[gi] = am[R0 + j]; gV[gi] = av[R0 + j]; }
+        }
     }
 }
 
@@ -329,60 +450,45 @@ __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned
     out[0] = r0 * c0f; out[1] = r0 * s0; out[2] = r1 * c1f; out[3] = r1 * s1;
 }
 
-// Gather one batch [x | u] (zero-padded to SA columns) into registers, element e = tid + j*256, in two
-// stages so that neither load latency is exposed: the row indices of the slots (issued one phase
-// earlier), then the elements (branch-free: out-of-range slots read a dummy address and are zeroed).
+// Next batch [x | u] into registers: thread = (row b = tid >> 3, column slice tid & 7), element j of the slice is
+// tile column (tid & 7) * NXU + j.  Branch-free: columns outside x / u read a dummy address and get their
+// constant (1 in the bias column, 0 elsewhere).
 template <class C>
-__device__ __forceinline__ void load_rows(int (&rows)[cdiv(FT_B * C::SA, FT_THREADS)], const int* idx) {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));      // keep the per-thread (row, column) decode out of the step loop's live set
-#pragma unroll
-    for (int j = 0; j < cdiv(FT_B * C::SA, FT_THREADS); ++j) {
-        const int b = (t + j * FT_THREADS) / C::SA;
-        rows[j] = idx[b < FT_B ? b : FT_B - 1];
-    }
-}
-
-template <class C>
-__device__ __forceinline__ void load_xu(float (&xu)[cdiv(FT_B * C::SA, FT_THREADS)],
-                                        const int (&rows)[cdiv(FT_B * C::SA, FT_THREADS)], const float* xd,
-                                        const float* ud) {
+__device__ __forceinline__ void load_xu(float (&xu)[C::NXU], int row, const float* xd, const float* ud) {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
+    const int k0 = (t & 7) * C::NXU;
 #pragma unroll
-    for (int j = 0; j < cdiv(FT_B * C::SA, FT_THREADS); ++j) {
-        const int e = t + j * FT_THREADS;
-        const int b = e / C::SA, k = e - b * C::SA;
-        const bool valid = b < FT_B && k < C::KIN;
-        const size_t row = (size_t)rows[j];
-        const float* p = k < C::DD ? xd + row * C::DD + k : ud + row * C::M + (k - C::DD);
-        const float val = *(valid ? p : xd);
-        xu[j] = valid ? val : 0.f;
+    for (int j = 0; j < C::NXU; ++j) {
+        const int k = k0 + j;
+        const bool is_x = k < C::DD, is_u = C::HAS_U && k >= C::UOFF && k < C::KIN;
+        const float* p = is_x ? xd + (size_t)row * C::DD + k : (is_u ? ud + (size_t)row * C::M + (k - C::UOFF) : xd);
+        const float val = *p;
+        xu[j] = (is_x || is_u) ? val : (k == C::KIN ? 1.f : 0.f);
     }
 }
 
 // ---------------------------------------------------------------------------------- kernel
-// 4 waves, one per SIMD (512-register budget each: Adam moments + stashed activations stay in
-// registers without spilling).  Every wave runs the same phase sequence on its own output blocks:
-//   2x2-tile block (r22, c22) of a 64x64 output, or row/column tile `rt` of a 16-wide head.
-// LDS tiles: A0..A3 activations / deltas, A4 = XU (forward) then gradient staging (backward).
 template <class C>
-__global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
+__global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* arena = lds;
-    float* A0 = arena + C::ARENA_PAD;
-    float* A1 = A0 + C::TILE;
-    float* A2 = A1 + C::TILE;
-    float* A3 = A2 + C::TILE;
-    float* A4 = A3 + C::TILE;
-    float* sG = A4 + C::TILE;
-    float* sV = sG + C::SMALL;
-    float* sL = sV + C::SMALL;
-    float* sZ = sL + C::SMALL;
-    float* csum = sZ + C::SMALL;         // 64 column sums (bias gradients); the slack also absorbs tile over-reads
-    float* red = csum + 64;              // 4 loss partials
+    float* T0 = arena + C::ARENA;
+    float* T1 = T0 + C::TILE;
+    float* T2 = T1 + C::TILE;
+    float* T3 = T2 + C::TILE;          // [x | u | 1] of the current batch, resident for the whole step
+    float* T4 = T3 + C::TILE;
+    float* sG = T4 + C::TILE;          // g, then dLoss/dg
+    float* sV = sG + C::SMALL;         // v = exp(logv), then dLoss/dlogv
+    float* sL = sV + C::SMALL;         // l = exp(logl), then dLoss/dlogl
+    float* sZ = sL + C::SMALL;         // eps, then z (with its constant-1 column), then the head-gradient stage
+    float* sO = T0;                    // dLoss/df (decoder head delta), D3..BF3
+    float* sD = T1;                    // dLoss/dz from the decoder, BF1..E
+    float* stF0 = T1 + C::SMALL;       // gradient stage of the decoder's first layer, BF1..E
+    float* red = stF0 + C::H * C::KS_F0;   // 8 loss partials, E..G3
 
-    constexpr int SA = C::SA, SS = C::SS, H = C::H, DD = C::DD, DL = C::DL, M = C::M, KIN = C::KIN;
+    constexpr int ST = C::ST, SS = C::SS, H = C::H, DD = C::DD, DL = C::DL, M = C::M;
+    constexpr int KS_H = C::KS_H, KS_E0 = C::KS_E0, KS_L0 = C::KS_L0, KS_F0 = C::KS_F0;
     const int tid = threadIdx.x;
     const int w_init = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int model = blockIdx.x;
@@ -395,53 +501,59 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
     const float slope = A.slope;
     const float wB = 1.f / (float)FT_B;
 
-    // ---- load state: zero LDS (finite padding), arena -> LDS, Adam moments -> registers
+    // ---- load state: zero LDS (padding must be finite and the bias/zero columns exact), parameters -> LDS,
+    // Adam moments -> registers
     for (int i = tid; i < C::LDS_FLOATS; i += FT_THREADS) lds[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < C::NPARAM; i += FT_THREADS) arena[i] = gP[i];
     float am[C::NADAM], av[C::NADAM];
     if (C::HAS_U) {
-        adam_load<C::P_L0, C::C_L0, C::R_L0>(gM + C::OFF_L0, gV + C::OFF_L0, am, av);
-        adam_load<C::P_L1, C::C_L1, C::R_L1>(gM + C::OFF_L1, gV + C::OFF_L1, am, av);
-        adam_load<C::P_L2, C::C_L2, C::R_L2>(gM + C::OFF_L2, gV + C::OFF_L2, am, av);
+        state_load<C, L_L0>(gP, gM, gV, arena, am, av);
+        state_load<C, L_L1>(gP, gM, gV, arena, am, av);
+        state_load<C, L_L2>(gP, gM, gV, arena, am, av);
     }
-    adam_load<C::P_F0, C::C_F0, C::R_F0>(gM + C::OFF_F0, gV + C::OFF_F0, am, av);
-    adam_load<C::P_F1, C::C_F1, C::R_F1>(gM + C::OFF_F1, gV + C::OFF_F1, am, av);
-    adam_load<C::P_F2, C::C_F2, C::R_F2>(gM + C::OFF_F2, gV + C::OFF_F2, am, av);
-    adam_load<C::P_E0, C::C_E0, C::R_G0>(gM + C::OFF_G0, gV + C::OFF_G0, am, av);
-    adam_load<C::P_E1, C::C_E1, C::R_G1>(gM + C::OFF_G1, gV + C::OFF_G1, am, av);
-    adam_load<C::P_E2, C::C_E2, C::R_G2>(gM + C::OFF_G2, gV + C::OFF_G2, am, av);
-    adam_load<C::P_E0, C::C_E0, C::R_V0>(gM + C::OFF_V0, gV + C::OFF_V0, am, av);
-    adam_load<C::P_E1, C::C_E1, C::R_V1>(gM + C::OFF_V1, gV + C::OFF_V1, am, av);
-    adam_load<C::P_E2, C::C_E2, C::R_V2>(gM + C::OFF_V2, gV + C::OFF_V2, am, av);
+    state_load<C, L_F0>(gP, gM, gV, arena, am, av);
+    state_load<C, L_F1>(gP, gM, gV, arena, am, av);
+    state_load<C, L_F2>(gP, gM, gV, arena, am, av);
+    state_load<C, L_G0>(gP, gM, gV, arena, am, av);
+    state_load<C, L_G1>(gP, gM, gV, arena, am, av);
+    state_load<C, L_G2>(gP, gM, gV, arena, am, av);
+    state_load<C, L_V0>(gP, gM, gV, arena, am, av);
+    state_load<C, L_V1>(gP, gM, gV, arena, am, av);
+    state_load<C, L_V2>(gP, gM, gV, arena, am, av);
     __syncthreads();
 
     const float w1 = A.w1, b2 = A.beta2, w2 = A.w2, aeps = A.adam_eps;
-    constexpr int NXU = cdiv(FT_B * C::SA, FT_THREADS);
-    float xu[NXU];
-    int rows[NXU];
-    load_rows<C>(rows, idxp);
-    load_xu<C>(xu, rows, xd, ud);
+    float xu[C::NXU];
+    load_xu<C>(xu, idxp[tid >> 3], xd, ud);
+    float neg_step = 0.f, inv_bc2 = 1.f;       // of the previous step (its last layer's Adam runs in P0)
+
+#define ADAM(L_, STAGE_) adam_layer<C, L_>(arena, STAGE_, am, av, w1, b2, w2, neg_step, inv_bc2, aeps)
 
     for (int s = 0; s < A.n_steps; ++s) {
-        // block coordinates (wave-uniform), re-derived per step behind an optimisation barrier so the
-        // scalar/vector address arithmetic of ~30 phases is not hoisted out of the step loop
+        // wave id / lane re-derived per step behind an optimisation barrier so the address arithmetic of ~20
+        // phases is not hoisted out of the step loop
         int w = w_init;
         asm volatile("" : "+s"(w));
         const int lane = opaque_lane();
-        const int r22 = (w >> 1) * 32, c22 = (w & 1) * 32;
-        const int rt = w * 16;
-        const float neg_step = A.neg_step[s], inv_bc2 = A.inv_bc2_sqrt[s];
-        const int* idx = idxp + (size_t)s * FT_B;
+        const int c = lane & 15, q = lane >> 4;
+        const int rt = w & 3;
 
         STAMP(0);
-        // ---- P0: the batch [x | u] was prefetched into registers during the previous step -> A4; eps -> sZ
+        // ---- P0: Adam of the previous step's last layer; [x | u | 1] (prefetched) -> T3; eps -> sZ
+        if (s > 0) {
+            if (C::HAS_U) ADAM(L_L0, T0); else ADAM(L_V0, T1);
+        }
+        neg_step = A.neg_step[s];
+        inv_bc2 = A.inv_bc2_sqrt[s];
+        {
+            float* dst = T3 + (tid >> 3) * ST + (tid & 7) * C::NXU;
 #pragma unroll
-        for (int j = 0; j < NXU; ++j) { const int e = tid + j * FT_THREADS; if (e < FT_B * SA) A4[e] = xu[j]; }
+            for (int j = 0; j < C::NXU; ++j) if ((tid & 7) * C::NXU + j < ST) dst[j] = xu[j];
+        }
         if (A.eps) {
-            for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
-                const int b = e / SS, k = e - b * SS;
-                if (k < DL) sZ[e] = A.eps[(((size_t)model * A.n_steps_total + A.step_begin + s) * FT_B + b) * DL + k];
+            for (int e = tid; e < FT_B * DL; e += FT_THREADS) {
+                const int b = e / DL, k = e - b * DL;
+                sZ[b * SS + k] = A.eps[(((size_t)model * A.n_steps_total + A.step_begin + s) * FT_B + b) * DL + k];
             }
         } else if (tid * 4 < FT_B * DL) {
             float nrm[4];
@@ -449,225 +561,226 @@ __global__ __launch_bounds__(FT_THREADS, 1) void k_train_steps(FusedArgs A) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const int el = tid * 4 + i; sZ[(el / DL) * SS + el % DL] = nrm[i]; }
         }
+        int next_row = 0;
+        if (s + 1 < A.n_steps) next_row = idxp[(size_t)(s + 1) * FT_B + (tid >> 3)];
         lds_barrier(); STAMP(1);
 
-        // ---- encoder g / logv layers 1-2; outputs stashed in registers for the backward pass
-        f32x4 st1g[2][2], st1v[2][2], st2g[2][2], st2v[2][2], st3[2][2], st4[2][2];
-        fwd_block<2, 2, 0>(A4, SA, arena + C::OFF_G0, KIN, arena + C::OFF_G0 + H * KIN, H, A0, SA, r22, c22, slope, st1g);
-        fwd_block<2, 2, 0>(A4, SA, arena + C::OFF_V0, KIN, arena + C::OFF_V0 + H * KIN, H, A1, SA, r22, c22, slope, st1v);
-        lds_barrier(); STAMP(2);
-        fwd_block<2, 2, 0>(A0, SA, arena + C::OFF_G1, H, arena + C::OFF_G1 + H * H, H, A2, SA, r22, c22, slope, st2g);
-        fwd_block<2, 2, 0>(A1, SA, arena + C::OFF_V1, H, arena + C::OFF_V1 + H * H, H, A3, SA, r22, c22, slope, st2v);
-        lds_barrier(); STAMP(3);
-        // ---- heads g -> sG, v = exp(logv) -> sV (row tile rt); prior layer 1 shares the phase (A0 is free)
+        // ---- F1: h1g -> T0, h1v -> T1 (one pass over the shared input)
+        f32x4 k1g[2], k1v[2], k2g[2], k2v[2], k1l[2], k2l[2];
         {
-            f32x4 acc[1][1];
-            fwd_block<1, 1, 1>(A2, SA, arena + C::OFF_G2, H, arena + C::OFF_G2 + DL * H, DL, sG, SS, rt, 0, slope, acc);
-            fwd_block<1, 1, 2>(A3, SA, arena + C::OFF_V2, H, arena + C::OFF_V2 + DL * H, DL, sV, SS, rt, 0, slope, acc);
+            const float* const W[2] = {arena + C::off_of(L_G0), arena + C::off_of(L_V0)};
+            float* const out[2] = {T0, T1};
+            f32x4 keep[2][2];
+            fwd_hidden<C, 2, KS_E0>(T3, ST, W, out, slope, w, keep);
+            k1g[0] = keep[0][0]; k1g[1] = keep[0][1]; k1v[0] = keep[1][0]; k1v[1] = keep[1][1];
         }
+        lds_barrier(); STAMP(2);
+        // ---- F2: h2g -> T2, h2v -> T4; next batch's rows start to arrive in registers
+        if (s + 1 < A.n_steps) load_xu<C>(xu, next_row, xd, ud);
+        {
+            const float* const Wg[1] = {arena + C::off_of(L_G1)};
+            float* const og[1] = {T2};
+            f32x4 keep[1][2];
+            fwd_hidden<C, 1, KS_H>(T0, ST, Wg, og, slope, w, keep);
+            k2g[0] = keep[0][0]; k2g[1] = keep[0][1];
+            const float* const Wv[1] = {arena + C::off_of(L_V1)};
+            float* const ov[1] = {T4};
+            fwd_hidden<C, 1, KS_H>(T1, ST, Wv, ov, slope, w, keep);
+            k2v[0] = keep[0][0]; k2v[1] = keep[0][1];
+        }
+        lds_barrier(); STAMP(3);
+        // ---- F3: heads g -> sG (waves 0-3), v = exp(logv) -> sV (waves 4-7); prior layer 1: h1l -> T0
+        if (w < 4) fwd_head<C, DL, false>(T2, arena + C::off_of(L_G2), sG, rt);
+        else fwd_head<C, DL, true>(T4, arena + C::off_of(L_V2), sV, rt);
         if (C::HAS_U) {
-            fwd_block<2, 2, 0>(A4 + DD, SA, arena + C::OFF_L0, M, arena + C::OFF_L0 + H * M, H, A0, SA, r22, c22, slope, st3);
-            lds_barrier(); STAMP(4);
-            fwd_block<2, 2, 0>(A0, SA, arena + C::OFF_L1, H, arena + C::OFF_L1 + H * H, H, A1, SA, r22, c22, slope, st4);
-            lds_barrier(); STAMP(5);
-            f32x4 acc[1][1];
-            fwd_block<1, 1, 2>(A1, SA, arena + C::OFF_L2, H, arena + C::OFF_L2 + DL * H, DL, sL, SS, rt, 0, slope, acc);
+            const float* const W[1] = {arena + C::off_of(L_L0)};
+            float* const out[1] = {T0};
+            f32x4 keep[1][2];
+            fwd_hidden<C, 1, KS_L0>(T3 + C::UOFF, ST, W, out, slope, w, keep);
+            k1l[0] = keep[0][0]; k1l[1] = keep[0][1];
         }
-        lds_barrier(); STAMP(6);
-        // ---- Z: reparameterisation + latent log-densities (nets.py:301-314)
-        float lsum = 0.f;
+        lds_barrier(); STAMP(4);
+        // ---- F4: prior layer 2: h2l -> T1; reparameterisation z = g + eps * sqrt(v) -> sZ (nets.py:301-304)
+        if (C::HAS_U) {
+            const float* const W[1] = {arena + C::off_of(L_L1)};
+            float* const out[1] = {T1};
+            f32x4 keep[1][2];
+            fwd_hidden<C, 1, KS_H>(T0, ST, W, out, slope, w, keep);
+            k2l[0] = keep[0][0]; k2l[1] = keep[0][1];
+        }
         for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
             const int b = e / SS, k = e - b * SS;
-            float zz = 0.f;
+            float zz = k == DL ? 1.f : 0.f;
             if (k < DL) {
-                const float ep = sZ[e];
-                const float gg = sG[e], vv = sV[e];
-                const float ll = C::HAS_U ? sL[e] : 1.f;
-                zz = ep * sqrtf(vv) + gg;
-                const float dq = zz - gg;
-                const float lqc = -0.5f * (LOG2PI_F + logf(vv) + dq * dq / vv);
-                const float lp = -0.5f * (LOG2PI_F + logf(ll) + zz * zz / ll);
-                lsum += A.d * lp - A.b * lqc;
-                if (!C::HAS_U) sL[e] = 1.f;
+                zz = sZ[e] * sqrtf(sV[e]) + sG[e];
                 if (A.z_out && s == A.n_steps - 1) A.z_out[((size_t)model * FT_B + b) * DL + k] = zz;
             }
             sZ[e] = zz;
         }
-        lds_barrier(); STAMP(7);
-        // ---- decoder f: z -> h1f (A0) -> h2f (A1) -> f; dOut = dLoss/df -> A2, log p(x|z)
+        lds_barrier(); STAMP(5);
+        // ---- F5: prior head l = exp(logl) -> sL (waves 0-3); decoder layer 1: h1f -> T2
+        if (C::HAS_U && w < 4) fwd_head<C, DL, true>(T1, arena + C::off_of(L_L2), sL, rt);
         {
-            f32x4 acc[2][2];
-            fwd_block<2, 2, 0>(sZ, SS, arena + C::OFF_F0, DL, arena + C::OFF_F0 + H * DL, H, A0, SA, r22, c22, slope, acc);
-            lds_barrier(); STAMP(8);
-            fwd_block<2, 2, 0>(A0, SA, arena + C::OFF_F1, H, arena + C::OFF_F1 + H * H, H, A1, SA, r22, c22, slope, acc);
-            lds_barrier(); STAMP(9);
+            const float* const W[1] = {arena + C::off_of(L_F0)};
+            float* const out[1] = {T2};
+            f32x4 keep[1][2];
+            fwd_hidden<C, 1, KS_F0>(sZ, SS, W, out, slope, w, keep);
         }
+        lds_barrier(); STAMP(6);
+        // ---- D2: h2f -> T4
         {
-            // A2 becomes the zero-padded dOut tile: columns >= 16 zeroed by everyone, the head tile written below
-            for (int e = tid; e < FT_B * SA; e += FT_THREADS) { const int k = e % SA; if (k >= 16) A2[e] = 0.f; }
-            f32x4 acc[1][1];
-            const int c = lane & 15, q = lane >> 4;
-            const float bv = c < DD ? arena[C::OFF_F2 + DD * H + c] : 0.f;
-            acc[0][0] = (f32x4){bv, bv, bv, bv};
-            mma_block<1, 1>(A1 + rt * SA, SA, 1, arena + C::OFF_F2, H, 1, pad4(H) / 4, acc);
+            const float* const W[1] = {arena + C::off_of(L_F1)};
+            float* const out[1] = {T4};
+            f32x4 keep[1][2];
+            fwd_hidden<C, 1, KS_H>(T2, ST, W, out, slope, w, keep);
+        }
+        lds_barrier(); STAMP(7);
+        // ---- D3: decoder head f, log p(x|z) and dLoss/df -> sO (waves 0-3)
+        float lsum = 0.f;
+        if (w < 4) {
+            const f32x4 acc = mm_fwd1<KS_H>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F2) + min(c, DD - 1) * KS_H, q);
             const float dv = A.decoder_var, logdv = logf(A.decoder_var);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = rt + 4 * q + r;
+                const int row = 16 * rt + 4 * q + r;
                 float dout = 0.f;
                 if (c < DD) {
-                    const float df = A4[row * SA + c] - acc[0][0][r];        // x - f
+                    const float df = T3[row * ST + c] - acc[r];             // x - f
                     lsum += A.a * (-0.5f * (LOG2PI_F + logdv + df * df / dv));
                     dout = -A.a * wB * df / dv;
                 }
-                A2[row * SA + c] = dout;
+                if (c < SS) sO[row * SS + c] = dout;
             }
         }
-        // loss reduction (deterministic): wave shuffle -> 4 partials -> thread 0
-        {
+        lds_barrier(); STAMP(8);
+
+        // ---- BF3: d2f -> T1; decoder-head gradient -> T0 + STG_F2 (waves 0-3)
+        dgrad_hidden<C, SS, DD, KS_H, H>(sO, SS, arena + C::off_of(L_F2), T4, T1, slope, w);
+        if (w < 4) wgrad_tile<C, DD, KS_H, H>(sO, SS, T4, ST, T0 + C::STG_F2, 0, w);
+        lds_barrier(); STAMP(9);
+        // ---- BF2: d1f -> T4; layer-2 gradient -> T0; Adam(F2)
+        dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_F1), T2, T4, slope, w);
+        wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w);
+        ADAM(L_F2, T0 + C::STG_F2);
+        lds_barrier(); STAMP(10);
+        // ---- BF1: dLoss/dz -> sD (waves 0-3); layer-1 gradient -> stF0 (waves 4-7); Adam(F1)
+        if (w < 4) {
+            const f32x4 acc = mm_dgrad1<KS_H, H, KS_F0>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F0) + min(c, KS_F0 - 1), q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (c < DL) sD[(16 * rt + 4 * q + r) * SS + c] = acc[r];
+        } else {
+            wgrad_tile<C, H, KS_F0, DL>(T4, ST, sZ, SS, stF0, w - 4, 0);
+        }
+        ADAM(L_F1, T0);
+        lds_barrier(); STAMP(11);
+        // ---- E: latent log-densities (nets.py:306-314) and head deltas in place (SURVEY §8 a-bwd):
+        //         sG <- dg, sV <- dlogv, sL <- dlogl; Adam(F0); h2g -> T2, h1g -> T4
+        for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
+            const int b = e / SS, k = e - b * SS;
+            float dg = 0.f, dv = 0.f, dl = 0.f;
+            if (k < DL) {
+                const float zz = sZ[e], gg = sG[e], vv = sV[e], ll = C::HAS_U ? sL[e] : 1.f;
+                const float dq = zz - gg;
+                const float rr = dq / vv;
+                const float lqc = -0.5f * (LOG2PI_F + logf(vv) + dq * rr);
+                const float lp = -0.5f * (LOG2PI_F + logf(ll) + zz * zz / ll);
+                lsum += A.d * lp - A.b * lqc;
+                const float Gz = sD[b * SS + k] - wB * (A.b * rr - A.d * zz / ll);
+                dg = wB * A.b * rr + Gz;
+                dv = -wB * A.b * 0.5f * (1.f - dq * rr) + Gz * 0.5f * dq;
+                dl = wB * A.d * 0.5f * (1.f - zz * zz / ll);
+            }
+            sG[e] = dg; sV[e] = dv;
+            if (C::HAS_U) sL[e] = dl;
+        }
+        ADAM(L_F0, stF0);
+        restore_tile<C>(k2g, T2, w);
+        restore_tile<C>(k1g, T4, w);
+        {   // loss reduction (deterministic): wave shuffle -> 8 partials -> thread 0 (next phase)
             float v = lsum;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0) red[w] = v;
         }
-        lds_barrier(); STAMP(10);
+        lds_barrier(); STAMP(12);
+
+        // ---- G3: d2g -> T0; head gradient -> sZ (z is dead); loss out
         if (tid == 0) {
-            const float t = (red[0] + red[1]) + (red[2] + red[3]);
+            const float t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
             A.loss_out[(size_t)model * A.n_steps_total + A.step_begin + s] = -t * wB;
         }
-
-#define ADAM(P_, NK_, CNT_, REG_, OFF_, DY_, SY_) \
-        adam_layer<P_, NK_, CNT_, REG_>(arena + OFF_, A4, csum, am, av, w1, b2, w2, neg_step, inv_bc2, aeps)
-
-        // ---- decoder backward.  layer 3: d2f -> A3
-        dgrad_block<2, 2, 1>(A2, SA, DD, arena + C::OFF_F2, H, A1, SA, A3, SA, r22, c22, slope);
-        wgrad_block<1, 1>(A2, SA, DD, A1, SA, H, A4, 0, rt);
-        colsum64(A2, SA, DD, csum, w);
-        lds_barrier(); STAMP(11);
-        ADAM(C::P_F2, DD * H, C::C_F2, C::R_F2, C::OFF_F2, A2, SA);
-        lds_barrier(); STAMP(12);
-        // layer 2: d1f -> A1
-        dgrad_block<2, 2, 1>(A3, SA, H, arena + C::OFF_F1, H, A0, SA, A1, SA, r22, c22, slope);
-        wgrad_block<2, 2>(A3, SA, H, A0, SA, H, A4, r22, c22);
-        colsum64(A3, SA, H, csum, w);
+        dgrad_hidden<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), T2, T0, slope, w);
+        if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
         lds_barrier(); STAMP(13);
-        ADAM(C::P_F1, H * H, C::C_F1, C::R_F1, C::OFF_F1, A3, SA);
+        // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
+        dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), T4, T2, slope, w);
+        wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w);
+        ADAM(L_G2, sZ);
         lds_barrier(); STAMP(14);
-        // layer 1: dz -> A2 (16 columns)
-        dgrad_block<1, 1, 0>(A1, SA, H, arena + C::OFF_F0, DL, nullptr, 0, A2, SA, rt, 0, slope);
-        wgrad_block<1, 1>(A1, SA, H, sZ, SS, DL, A4, rt, 0);
-        colsum64(A1, SA, H, csum, w);
+        // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
+        wgrad_pair<C, H, KS_E0, C::KIN>(T2, ST, T3, ST, T0, w);
+        ADAM(L_G1, T1);
+        restore_tile<C>(k2v, T4, w);
         lds_barrier(); STAMP(15);
-        ADAM(C::P_F0, H * DL, C::C_F0, C::R_F0, C::OFF_F0, A1, SA);
-        // ---- E: head deltas in place (SURVEY §8 a-bwd): sG <- dg, sV <- dlogv, sL <- dlogl
-        for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
-            const int b = e / SS, k = e - b * SS;
-            float dg = 0.f, dv = 0.f, dl = 0.f;
-            if (k < DL) {
-                const float zz = sZ[e], gg = sG[e], vv = sV[e], ll = sL[e];
-                const float dq = zz - gg;
-                const float rr = dq / vv;
-                const float Gz = A2[b * SA + k] - wB * (A.b * rr - A.d * zz / ll);
-                dg = wB * A.b * rr + Gz;
-                dv = -wB * A.b * 0.5f * (1.f - dq * rr) + Gz * 0.5f * dq;
-                dl = wB * A.d * 0.5f * (1.f - zz * zz / ll);
-            }
-            sG[e] = dg; sV[e] = dv; sL[e] = dl;
-        }
-        // restore g's hidden activations: h2g -> A0 (h1f dead), h1g -> A3 (d2f dead).  A1 is still read by the
-        // bias sums of the decoder's first layer above, A2 (dz) by the delta loop.
-        restore_block<2, 2>(st2g, A0, SA, r22, c22);
-        restore_block<2, 2>(st1g, A3, SA, r22, c22);
+
+        // ---- V3: d2v -> T1; head gradient -> sZ; Adam(G0); h1v -> T2
+        dgrad_hidden<C, SS, DL, KS_H, H>(sV, SS, arena + C::off_of(L_V2), T4, T1, slope, w);
+        if (w < 4) wgrad_tile<C, DL, KS_H, H>(sV, SS, T4, ST, sZ, 0, w);
+        ADAM(L_G0, T0);
+        restore_tile<C>(k1v, T2, w);
         lds_barrier(); STAMP(16);
-
-        // ---- g backward: d2g -> A2, d1g -> A1
-        if (s + 1 < A.n_steps) load_rows<C>(rows, idx + FT_B);     // next batch's row indices, used one phase later
-        dgrad_block<2, 2, 1>(sG, SS, DL, arena + C::OFF_G2, H, A0, SA, A2, SA, r22, c22, slope);
-        wgrad_block<1, 1>(sG, SS, DL, A0, SA, H, A4, 0, rt);
-        colsum64(sG, SS, DL, csum, w);
+        // ---- V2: d1v -> T4; layer-2 gradient -> T0; Adam(V2)
+        dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), T2, T4, slope, w);
+        wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w);
+        ADAM(L_V2, sZ);
         lds_barrier(); STAMP(17);
-        ADAM(C::P_E2, DL * H, C::C_E2, C::R_G2, C::OFF_G2, sG, SS);
+        // ---- V1: layer-1 gradient -> T1; Adam(V1); h2l -> T2
+        wgrad_pair<C, H, KS_E0, C::KIN>(T4, ST, T3, ST, T1, w);
+        ADAM(L_V1, T0);
+        if (C::HAS_U) restore_tile<C>(k2l, T2, w);
         lds_barrier(); STAMP(18);
-        dgrad_block<2, 2, 1>(A2, SA, H, arena + C::OFF_G1, H, A3, SA, A1, SA, r22, c22, slope);
-        wgrad_block<2, 2>(A2, SA, H, A3, SA, H, A4, r22, c22);
-        // XU again (registers -> A0, h2g is dead) for the first-layer weight gradients of g / logv / logl,
-        // then start fetching the next step's batch: its latency hides behind the rest of this step
-#pragma unroll
-        for (int j = 0; j < NXU; ++j) { const int e = tid + j * FT_THREADS; if (e < FT_B * SA) A0[e] = xu[j]; }
-        if (s + 1 < A.n_steps) load_xu<C>(xu, rows, xd, ud);
-        colsum64(A2, SA, H, csum, w);
-        lds_barrier(); STAMP(19);
-        ADAM(C::P_E1, H * H, C::C_E1, C::R_G1, C::OFF_G1, A2, SA);
-        lds_barrier(); STAMP(20);
-        wgrad_block<2, 2>(A1, SA, H, A0, SA, KIN, A4, r22, c22);
-        colsum64(A1, SA, H, csum, w);
-        lds_barrier(); STAMP(21);
-        ADAM(C::P_E0, H * KIN, C::C_E0, C::R_G0, C::OFF_G0, A1, SA);
-        // restore logv's hidden activations: h2v -> A2 (d2g dead), h1v -> A3 (h1g dead); A1 busy (bias sums)
-        restore_block<2, 2>(st2v, A2, SA, r22, c22);
-        restore_block<2, 2>(st1v, A3, SA, r22, c22);
-        lds_barrier(); STAMP(22);
 
-        // ---- logv backward: d2v -> A1, d1v -> A2
-        dgrad_block<2, 2, 1>(sV, SS, DL, arena + C::OFF_V2, H, A2, SA, A1, SA, r22, c22, slope);
-        wgrad_block<1, 1>(sV, SS, DL, A2, SA, H, A4, 0, rt);
-        colsum64(sV, SS, DL, csum, w);
-        lds_barrier(); STAMP(23);
-        ADAM(C::P_E2, DL * H, C::C_E2, C::R_V2, C::OFF_V2, sV, SS);
-        lds_barrier(); STAMP(24);
-        dgrad_block<2, 2, 1>(A1, SA, H, arena + C::OFF_V1, H, A3, SA, A2, SA, r22, c22, slope);
-        wgrad_block<2, 2>(A1, SA, H, A3, SA, H, A4, r22, c22);
-        colsum64(A1, SA, H, csum, w);
-        lds_barrier(); STAMP(25);
-        ADAM(C::P_E1, H * H, C::C_E1, C::R_V1, C::OFF_V1, A1, SA);
-        lds_barrier(); STAMP(26);
-        wgrad_block<2, 2>(A2, SA, H, A0, SA, KIN, A4, r22, c22);
-        colsum64(A2, SA, H, csum, w);
-        lds_barrier(); STAMP(27);
-        ADAM(C::P_E0, H * KIN, C::C_E0, C::R_V0, C::OFF_V0, A2, SA);
-
-        // ---- logl backward: h2l -> A1 (d2v dead), h1l -> A3 (h1v dead); d2l -> A2 (after the sync), d1l -> A1
         if (C::HAS_U) {
-            restore_block<2, 2>(st4, A1, SA, r22, c22);
-            restore_block<2, 2>(st3, A3, SA, r22, c22);
-            lds_barrier(); STAMP(28);
-            dgrad_block<2, 2, 1>(sL, SS, DL, arena + C::OFF_L2, H, A1, SA, A2, SA, r22, c22, slope);
-            wgrad_block<1, 1>(sL, SS, DL, A1, SA, H, A4, 0, rt);
-            colsum64(sL, SS, DL, csum, w);
-            lds_barrier(); STAMP(29);
-            ADAM(C::P_L2, DL * H, C::C_L2, C::R_L2, C::OFF_L2, sL, SS);
-            lds_barrier(); STAMP(30);
-            dgrad_block<2, 2, 1>(A2, SA, H, arena + C::OFF_L1, H, A3, SA, A1, SA, r22, c22, slope);
-            wgrad_block<2, 2>(A2, SA, H, A3, SA, H, A4, r22, c22);
-            colsum64(A2, SA, H, csum, w);
-            lds_barrier(); STAMP(31);
-            ADAM(C::P_L1, H * H, C::C_L1, C::R_L1, C::OFF_L1, A2, SA);
-            lds_barrier(); STAMP(32);
-            wgrad_block<2, 2>(A1, SA, H, A0 + DD, SA, M, A4, r22, c22);
-            colsum64(A1, SA, H, csum, w);
-            lds_barrier(); STAMP(33);
-            ADAM(C::P_L0, H * M, C::C_L0, C::R_L0, C::OFF_L0, A1, SA);
+            // ---- L3: d2l -> T0; head gradient -> sZ; Adam(V0); h1l -> T4
+            dgrad_hidden<C, SS, DL, KS_H, H>(sL, SS, arena + C::off_of(L_L2), T2, T0, slope, w);
+            if (w < 4) wgrad_tile<C, DL, KS_H, H>(sL, SS, T2, ST, sZ, 0, w);
+            ADAM(L_V0, T1);
+            restore_tile<C>(k1l, T4, w);
+            lds_barrier(); STAMP(19);
+            // ---- L2: d1l -> T2; layer-2 gradient -> T1; Adam(L2)
+            dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), T4, T2, slope, w);
+            wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w);
+            ADAM(L_L2, sZ);
+            lds_barrier(); STAMP(20);
+            // ---- L1: layer-1 gradient -> T0; Adam(L1)
+            wgrad_pair<C, H, KS_L0, M>(T2, ST, T3 + C::UOFF, ST, T0, w);
+            ADAM(L_L1, T1);
+            lds_barrier(); STAMP(21);
         }
-#undef ADAM
-        lds_barrier();
     }
+    // Adam of the last step's last layer
+    if (A.n_steps > 0) {
+        if (C::HAS_U) ADAM(L_L0, T0); else ADAM(L_V0, T1);
+    }
+#undef ADAM
+    __syncthreads();
 
     // ---- write state back
-    for (int i = tid; i < C::NPARAM; i += FT_THREADS) gP[i] = arena[i];
     if (C::HAS_U) {
-        adam_store<C::P_L0, C::C_L0, C::R_L0>(gM + C::OFF_L0, gV + C::OFF_L0, am, av);
-        adam_store<C::P_L1, C::C_L1, C::R_L1>(gM + C::OFF_L1, gV + C::OFF_L1, am, av);
-        adam_store<C::P_L2, C::C_L2, C::R_L2>(gM + C::OFF_L2, gV + C::OFF_L2, am, av);
+        state_store<C, L_L0>(gP, gM, gV, arena, am, av);
+        state_store<C, L_L1>(gP, gM, gV, arena, am, av);
+        state_store<C, L_L2>(gP, gM, gV, arena, am, av);
     }
-    adam_store<C::P_F0, C::C_F0, C::R_F0>(gM + C::OFF_F0, gV + C::OFF_F0, am, av);
-    adam_store<C::P_F1, C::C_F1, C::R_F1>(gM + C::OFF_F1, gV + C::OFF_F1, am, av);
-    adam_store<C::P_F2, C::C_F2, C::R_F2>(gM + C::OFF_F2, gV + C::OFF_F2, am, av);
-    adam_store<C::P_E0, C::C_E0, C::R_G0>(gM + C::OFF_G0, gV + C::OFF_G0, am, av);
-    adam_store<C::P_E1, C::C_E1, C::R_G1>(gM + C::OFF_G1, gV + C::OFF_G1, am, av);
-    adam_store<C::P_E2, C::C_E2, C::R_G2>(gM + C::OFF_G2, gV + C::OFF_G2, am, av);
-    adam_store<C::P_E0, C::C_E0, C::R_V0>(gM + C::OFF_V0, gV + C::OFF_V0, am, av);
-    adam_store<C::P_E1, C::C_E1, C::R_V1>(gM + C::OFF_V1, gV + C::OFF_V1, am, av);
-    adam_store<C::P_E2, C::C_E2, C::R_V2>(gM + C::OFF_V2, gV + C::OFF_V2, am, av);
+    state_store<C, L_F0>(gP, gM, gV, arena, am, av);
+    state_store<C, L_F1>(gP, gM, gV, arena, am, av);
+    state_store<C, L_F2>(gP, gM, gV, arena, am, av);
+    state_store<C, L_G0>(gP, gM, gV, arena, am, av);
+    state_store<C, L_G1>(gP, gM, gV, arena, am, av);
+    state_store<C, L_G2>(gP, gM, gV, arena, am, av);
+    state_store<C, L_V0>(gP, gM, gV, arena, am, av);
+    state_store<C, L_V1>(gP, gM, gV, arena, am, av);
+    state_store<C, L_V2>(gP, gM, gV, arena, am, av);
 }
 
 // ------------------------------------------------------------------------------ host side
@@ -684,7 +797,9 @@ static hipError_t launch_cfg(const FusedArgs& A, int n_models, hipStream_t st) {
     return hipGetLastError();
 }
 
+#ifndef FT_SHAPES
 #define FT_SHAPES(X) X(10, 10, 40, 50) X(10, 10, 0, 50) X(5, 5, 40, 50) X(5, 5, 0, 50)
+#endif
 
 #ifdef FT_PROF
 extern "C" int ivae_debug_set_prof(void* buf) {

@@ -13,11 +13,10 @@ import torch
 from ivae_amd import _lib, ops
 from ivae_amd.trainer import FusedPackedTrainer
 
-LABELS = ["P0 gather", "F1 enc L1 (g,v)", "F2 enc L2", "F3 heads + L1 prior", "L2 prior", "L3 prior head", "Z reparam",
-          "D1 dec L1", "D2 dec L2", "D3 dec head+loss", "DB3 compute", "DB3 adam", "DB2 compute", "DB2 adam",
-          "DB1 compute", "DB1 adam+E+restore g", "GB3 compute", "GB3 adam", "GB2 compute+reload XU", "GB2 adam",
-          "GB1 compute", "GB1 adam+restore v", "VB3 compute", "VB3 adam", "VB2 compute", "VB2 adam", "VB1 compute",
-          "VB1 adam+restore l", "LB3 compute", "LB3 adam", "LB2 compute", "LB2 adam", "LB1 compute", "LB1 adam"]
+LABELS = ["P0 adam(last) + XU/eps -> LDS", "F1 enc L1 (g,v)", "F2 enc L2 (g,v)", "F3 heads g,v + prior L1", "F4 prior L2 + z",
+          "F5 prior head + dec L1", "D2 dec L2", "D3 dec head + loss", "BF3 dgrad+wgrad head", "BF2 dgrad+wgrad+adam",
+          "BF1 dz | wgrad + adam", "E deltas + adam + restore", "G3", "G2", "G1", "V3", "V2", "V1", "L3", "L2", "L1"]
+NSEG = len(LABELS)
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = 24
@@ -34,7 +33,7 @@ buf = torch.zeros(steps * 64, dtype=torch.int64, device=dev)
 assert _lib.lib().ivae_debug_set_prof(C.c_void_p(buf.data_ptr())) == 0
 tr.run(steps)
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(steps, 64)[:, :34].astype(np.float64)
+t = buf.cpu().numpy().reshape(steps, 64)[:, :NSEG].astype(np.float64)
 seg = np.diff(np.concatenate([t[:-1], t[1:, :1]], 1), axis=1)[4:]      # (steps-1, 34) cycles per segment
 mean = seg.mean(0)
 tot = mean.sum()
