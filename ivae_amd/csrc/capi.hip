@@ -120,6 +120,7 @@ int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float
 
 int ivae_train_steps_supported(const IvaeDims* d) {
     if (ivae_check_dims(d) != IVAE_OK) return 0;
+    if (!(d->slope >= 0.f && d->slope <= 1.f)) return 0;      // the fused kernel computes lrelu as max(p, slope*p)
     return fused_supported(d->data_dim, d->latent_dim, d->aux_dim, d->hidden_dim, d->n_layers, d->activation, d->batch) ? 1 : 0;
 }
 

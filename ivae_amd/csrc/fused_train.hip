@@ -112,32 +112,63 @@ __device__ __forceinline__ int opaque_lane() {
 // step loop go through LDS; __syncthreads() would also drain vmcnt and so expose the latency of the
 // next batch's prefetch (global loads into registers that nothing reads until the next step).
 __device__ __forceinline__ void lds_barrier() {
+#ifdef FT_ABL_NOBARRIER       // timing experiment only (results are wrong)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#ifdef FT_ABL_NOMFMA          // timing experiment only: one VALU op in place of the matrix instruction
+    c[0] += a * b;
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
 __device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = (f32x2){a, b}; }
-__device__ __forceinline__ float lrelu(float p, float slope) { return p > 0.f ? p : p * slope; }
+// leaky ReLU for 0 <= slope <= 1 (checked on the host before launch): max(p, slope * p)
+__device__ __forceinline__ float lrelu(float p, float slope) { return fmaxf(p, p * slope); }
+
+// natural log on the hardware log2 unit (v_log_f32, 1 ulp in log2)
+__device__ __forceinline__ float flog(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
 
 #define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
 
+// Phase body in two halves executed in opposite order by the two waves of a SIMD (waves w and w+4 share one):
+// while waves 0-3 run the matrix half, waves 4-7 run the vector half (Adam, restores), then they swap, so the
+// matrix pipe and the VALU of every SIMD are busy together.  One copy of the code: a 2-trip loop whose branch
+// is wave-uniform.  The halves must not depend on each other (they run concurrently on other waves anyway).
+template <class FM, class FV>
+__device__ __forceinline__ void stagger(int w, FM&& matrix_half, FV&& vector_half) {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if ((half == 0) == (w < 4)) matrix_half(); else vector_half();
+    }
+}
+#define LAMBDA [&]() __attribute__((always_inline))
+
+
 // ---- products.  c = lane & 15, q = lane >> 4.  MFMA operand slots: A[i = c][k = q], B[k = q][j = c];
 // result: C[i = 4q + r][j = c], r = 0..3.
+
+// The compiler's scheduler sinks LDS reads down to their first use, which exposes the full LDS latency in front
+// of every group of MFMAs.  Each product below therefore issues the operand reads of group t+1 BEFORE the MFMAs
+// of group t and pins that order with scheduling barriers; the wait-count pass then emits counted lgkmcnt waits.
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // acc[w][j] += X[row][k] * W_w[n_j][k], k in [0, KS), KS = 8G + 4.  xrow = X + row*sx, wrow[w][j] = W_w + n_j*KS.
 template <int NW, int KS>
 __device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&wrow)[NW][2], int q, f32x4 (&acc)[NW][2]) {
     constexpr int G = (KS - 4) / 8;
-    static_assert(KS == 8 * G + 4, "row strides are 4*odd");
+    static_assert(KS == 8 * G + 4 && G >= 1, "row strides are 4*odd, >= 12");
     f32x2 a[2], b[2][NW][2];
-    if (G > 0) {
-        a[0] = ld2(xrow + 2 * q);
+    float at = 0.f, bt[NW][2];
+    a[0] = ld2(xrow + 2 * q);
 #pragma unroll
-        for (int w = 0; w < NW; ++w) { b[0][w][0] = ld2(wrow[w][0] + 2 * q); b[0][w][1] = ld2(wrow[w][1] + 2 * q); }
-    }
+    for (int w = 0; w < NW; ++w) { b[0][w][0] = ld2(wrow[w][0] + 2 * q); b[0][w][1] = ld2(wrow[w][1] + 2 * q); }
 #pragma unroll
     for (int t = 0; t < G; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
@@ -148,32 +179,36 @@ __device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&w
                 b[nxt][w][0] = ld2(wrow[w][0] + 8 * (t + 1) + 2 * q);
                 b[nxt][w][1] = ld2(wrow[w][1] + 8 * (t + 1) + 2 * q);
             }
+        } else {
+            at = xrow[8 * G + q];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { bt[w][0] = wrow[w][0][8 * G + q]; bt[w][1] = wrow[w][1][8 * G + q]; }
         }
+        SCHED_FENCE();
 #pragma unroll
         for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(a[cur].x, b[cur][w][0].x, acc[w][0]); acc[w][1] = mfma4(a[cur].x, b[cur][w][1].x, acc[w][1]); }
 #pragma unroll
         for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(a[cur].y, b[cur][w][0].y, acc[w][0]); acc[w][1] = mfma4(a[cur].y, b[cur][w][1].y, acc[w][1]); }
+        SCHED_FENCE();
     }
-    const float at = xrow[8 * G + q];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        acc[w][0] = mfma4(at, wrow[w][0][8 * G + q], acc[w][0]);
-        acc[w][1] = mfma4(at, wrow[w][1][8 * G + q], acc[w][1]);
-    }
+    for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(at, bt[w][0], acc[w][0]); acc[w][1] = mfma4(at, bt[w][1], acc[w][1]); }
 }
 
-// single 16-wide tile: acc += X[row][k] * W[n][k]; two accumulators break the dependent chain
+// single 16-wide tile: acc += X[row][k] * W[n][k]; all operands are read up front (2G+2 registers), two
+// accumulators break the dependent chain
 template <int KS>
 __device__ __forceinline__ f32x4 mm_fwd1(const float* xrow, const float* wrow, int q) {
     constexpr int G = (KS - 4) / 8;
+    f32x2 a[G], b[G];
+#pragma unroll
+    for (int t = 0; t < G; ++t) { a[t] = ld2(xrow + 8 * t + 2 * q); b[t] = ld2(wrow + 8 * t + 2 * q); }
+    const float at = xrow[8 * G + q], bt = wrow[8 * G + q];
+    SCHED_FENCE();
     f32x4 e = ZERO4, o = ZERO4;
 #pragma unroll
-    for (int t = 0; t < G; ++t) {
-        const f32x2 a = ld2(xrow + 8 * t + 2 * q), b = ld2(wrow + 8 * t + 2 * q);
-        e = mfma4(a.x, b.x, e);
-        o = mfma4(a.y, b.y, o);
-    }
-    e = mfma4(xrow[8 * G + q], wrow[8 * G + q], e);
+    for (int t = 0; t < G; ++t) { e = mfma4(a[t].x, b[t].x, e); o = mfma4(a[t].y, b[t].y, o); }
+    e = mfma4(at, bt, e);
     return e + o;
 }
 
@@ -182,63 +217,95 @@ __device__ __forceinline__ f32x4 mm_fwd1(const float* xrow, const float* wrow, i
 template <int NS, int N, int KS>
 __device__ __forceinline__ void mm_dgrad(const float* yrow, const float* wcol, int q, f32x4 (&acc)[2]) {
     constexpr int G = (NS - 4) / 8;
-    static_assert(NS == 8 * G + 4, "contraction lengths are 4*odd");
+    static_assert(NS == 8 * G + 4 && G >= 1, "contraction lengths are 4*odd, >= 12");
+    f32x2 a[2], b0[2], b1[2], bt = {0.f, 0.f};
+    float at = 0.f;
+    auto rows = [&](int t, int& n0, int& n1) {
+        n0 = 8 * t + 2 * q; n1 = n0 + 1;
+        if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
+    };
+    {
+        int n0, n1; rows(0, n0, n1);
+        a[0] = ld2(yrow + 2 * q); b0[0] = ld2(wcol + n0 * KS); b1[0] = ld2(wcol + n1 * KS);
+    }
 #pragma unroll
     for (int t = 0; t < G; ++t) {
-        const f32x2 a = ld2(yrow + 8 * t + 2 * q);
-        int n0 = 8 * t + 2 * q, n1 = n0 + 1;
-        if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
-        const f32x2 b0 = ld2(wcol + n0 * KS), b1 = ld2(wcol + n1 * KS);
-        acc[0] = mfma4(a.x, b0.x, acc[0]);
-        acc[1] = mfma4(a.x, b0.y, acc[1]);
-        acc[0] = mfma4(a.y, b1.x, acc[0]);
-        acc[1] = mfma4(a.y, b1.y, acc[1]);
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (t + 1 < G) {
+            int n0, n1; rows(t + 1, n0, n1);
+            a[nxt] = ld2(yrow + 8 * (t + 1) + 2 * q); b0[nxt] = ld2(wcol + n0 * KS); b1[nxt] = ld2(wcol + n1 * KS);
+        } else {
+            int n = 8 * G + q;
+            if (8 * G + 3 >= N) n = min(n, N - 1);
+            at = yrow[8 * G + q]; bt = ld2(wcol + n * KS);
+        }
+        SCHED_FENCE();
+        acc[0] = mfma4(a[cur].x, b0[cur].x, acc[0]);
+        acc[1] = mfma4(a[cur].x, b0[cur].y, acc[1]);
+        acc[0] = mfma4(a[cur].y, b1[cur].x, acc[0]);
+        acc[1] = mfma4(a[cur].y, b1[cur].y, acc[1]);
+        SCHED_FENCE();
     }
-    const float a = yrow[8 * G + q];
-    int n = 8 * G + q;
-    if (8 * G + 3 >= N) n = min(n, N - 1);
-    const f32x2 b = ld2(wcol + n * KS);
-    acc[0] = mfma4(a, b.x, acc[0]);
-    acc[1] = mfma4(a, b.y, acc[1]);
+    acc[0] = mfma4(at, bt.x, acc[0]);
+    acc[1] = mfma4(at, bt.y, acc[1]);
 }
 
-// single tile, scalar column: acc += dY[row][n] * W[n][col]
+// single tile, scalar column: acc += dY[row][n] * W[n][col]; operands read up front
 template <int NS, int N, int KS>
 __device__ __forceinline__ f32x4 mm_dgrad1(const float* yrow, const float* wcol, int q) {
     constexpr int G = (NS - 4) / 8;
-    f32x4 e = ZERO4, o = ZERO4;
+    f32x2 a[G];
+    float b0[G], b1[G];
 #pragma unroll
     for (int t = 0; t < G; ++t) {
-        const f32x2 a = ld2(yrow + 8 * t + 2 * q);
         int n0 = 8 * t + 2 * q, n1 = n0 + 1;
         if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
-        e = mfma4(a.x, wcol[n0 * KS], e);
-        o = mfma4(a.y, wcol[n1 * KS], o);
+        a[t] = ld2(yrow + 8 * t + 2 * q); b0[t] = wcol[n0 * KS]; b1[t] = wcol[n1 * KS];
     }
     int n = 8 * G + q;
     if (8 * G + 3 >= N) n = min(n, N - 1);
-    e = mfma4(yrow[8 * G + q], wcol[n * KS], e);
+    const float at = yrow[8 * G + q], bt = wcol[n * KS];
+    SCHED_FENCE();
+    f32x4 e = ZERO4, o = ZERO4;
+#pragma unroll
+    for (int t = 0; t < G; ++t) { e = mfma4(a[t].x, b0[t], e); o = mfma4(a[t].y, b1[t], o); }
+    e = mfma4(at, bt, e);
     return e + o;
 }
 
-// acc[j] += dY[b][n] * X[b][col0 + j], b in [0, 64).  ycol = dY + n, xcol = X + col0.
+// acc[j] += dY[b][n] * X[b][col0 + j], b in [0, 64).  ycol = dY + n, xcol = X + col0.  Groups of 4 batch k-steps.
 __device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float* xcol, int sx, int q, f32x4 (&acc)[2]) {
+    constexpr int G = FT_B / 16;
+    float a[2][4];
+    f32x2 b[2][4];
 #pragma unroll
-    for (int t = 0; t < FT_B / 4; ++t) {
-        const float a = ycol[(4 * t + q) * sy];
-        const f32x2 b = ld2(xcol + (4 * t + q) * sx);
-        acc[0] = mfma4(a, b.x, acc[0]);
-        acc[1] = mfma4(a, b.y, acc[1]);
+    for (int i = 0; i < 4; ++i) { a[0][i] = ycol[(4 * i + q) * sy]; b[0][i] = ld2(xcol + (4 * i + q) * sx); }
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        if (t + 1 < G) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[nxt][i] = ycol[(16 * (t + 1) + 4 * i + q) * sy];
+                b[nxt][i] = ld2(xcol + (16 * (t + 1) + 4 * i + q) * sx);
+            }
+        }
+        SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[0] = mfma4(a[cur][i], b[cur][i].x, acc[0]); acc[1] = mfma4(a[cur][i], b[cur][i].y, acc[1]); }
+        SCHED_FENCE();
     }
 }
 
+// single tile: operands of all 16 k-steps read up front (32 registers)
 __device__ __forceinline__ f32x4 mm_wgrad1(const float* ycol, int sy, const float* xcol, int sx, int q) {
+    float a[FT_B / 4], b[FT_B / 4];
+#pragma unroll
+    for (int t = 0; t < FT_B / 4; ++t) { a[t] = ycol[(4 * t + q) * sy]; b[t] = xcol[(4 * t + q) * sx]; }
+    SCHED_FENCE();
     f32x4 e = ZERO4, o = ZERO4;
 #pragma unroll
-    for (int t = 0; t < FT_B / 4; t += 2) {
-        e = mfma4(ycol[(4 * t + q) * sy], xcol[(4 * t + q) * sx], e);
-        o = mfma4(ycol[(4 * t + 4 + q) * sy], xcol[(4 * t + 4 + q) * sx], o);
-    }
+    for (int t = 0; t < FT_B / 4; t += 2) { e = mfma4(a[t], b[t], e); o = mfma4(a[t + 1], b[t + 1], o); }
     return e + o;
 }
 
@@ -319,6 +386,25 @@ __device__ __forceinline__ void dgrad_hidden(const float* dY, int sy, const floa
     }
 }
 
+// Same with the activation mask taken from the wave's stash registers (same (row, column) mapping as the
+// epilogue of fwd_hidden): no LDS read, and the activation tile need not be restored for it.
+template <class C, int NS, int N, int KS, int KB>
+__device__ __forceinline__ void dgrad_hidden_reg(const float* dY, int sy, const float* W, const f32x4 (&keep)[2], float* out,
+                                                 float slope, int w) {
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    f32x4 acc[2] = {ZERO4, ZERO4};
+    mm_dgrad<NS, N, KS>(dY + (16 * rt + c) * sy, W + min(col0, KS - 2), q, acc);
+    const bool in0 = col0 < KB, in1 = col0 + 1 < KB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v0 = in0 ? acc[0][r] * (keep[0][r] > 0.f ? 1.f : slope) : 0.f;
+        const float v1 = in1 ? acc[1][r] * (keep[1][r] > 0.f ? 1.f : slope) : 0.f;
+        if (col0 < C::ST) st2(out + (16 * rt + 4 * q + r) * C::ST + col0, v0, v1);
+    }
+}
+
 // Weight gradient of a layer with > 16 input columns: stage[n][k] = sum_b dY[b][n] X[b][k] for k <= KB (k == KB
 // is the bias gradient: X carries a constant-1 column there), 0 beyond.  Wave w: rows 16*(w&3).., column half w>>2.
 template <class C, int N, int KS, int KB>
@@ -330,8 +416,8 @@ __device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float*
     mm_wgrad(dY + min(16 * nt + c, sy - 1), sy, X + min(col0, KS - 2), sx, q, acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int n = 16 * nt + 4 * q + r;
-        if (n < N && col0 < KS) st2(stage + n * KS + col0, col0 <= KB ? acc[0][r] : 0.f, col0 + 1 <= KB ? acc[1][r] : 0.f);
+        const int n = 16 * nt + 4 * q + r;       // rows >= N land in the unused tail of the (64-row) stage tile
+        if (col0 < KS) st2(stage + n * KS + col0, col0 <= KB ? acc[0][r] : 0.f, col0 + 1 <= KB ? acc[1][r] : 0.f);
     }
 }
 
@@ -355,24 +441,34 @@ __device__ __forceinline__ void wgrad_tile(const float* dY, int sy, const float*
 template <class C, int L, int NA>
 __device__ __forceinline__ void adam_layer(float* arena, const float* stage, float (&am)[NA], float (&av)[NA], float w1,
                                            float b2, float w2, float neg_step, float inv_bc2, float eps) {
-    constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L);
-    float* base = arena + C::off_of(L);
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
+    constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L), CNT = C::cnt_of(L);
+    if constexpr (CNT > 0) {
+        float* base = arena + C::off_of(L);
+        unsigned t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        // Branch-free: out-of-range slots work on a clamped (valid) element and only skip the store; their moment
+        // registers hold garbage that is never written back.  All LDS reads of the layer are issued before any math.
+        unsigned off[CNT];
+        float g[CNT], p[CNT];
 #pragma unroll
-    for (int j = 0; j < C::cnt_of(L); ++j) {
-        const int idx = t + j * FT_THREADS;
-        if (idx < P) {
-            const int n = idx / KC;
-            const int off = n * KS + (idx - n * KC);
-            const float g = stage[off];
+        for (int j = 0; j < CNT; ++j) {
+            const unsigned idx = min(t + j * FT_THREADS, (unsigned)(P - 1));
+            const unsigned n = idx / (unsigned)KC;
+            off[j] = n * KS + (idx - n * KC);
+            g[j] = stage[off[j]];
+            p[j] = base[off[j]];
+        }
+        SCHED_FENCE();
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
             const float m0 = am[R0 + j], v0 = av[R0 + j];
-            const float mi = m0 + w1 * (g - m0);
-            const float vi = v0 * b2 + (w2 * g) * g;
+            const float mi = m0 + w1 * (g[j] - m0);
+            const float vi = v0 * b2 + (w2 * g[j]) * g[j];
             const float denom = __builtin_amdgcn_sqrtf(vi) * inv_bc2 + eps;
-            base[off] = base[off] + (neg_step * mi) * __builtin_amdgcn_rcpf(denom);
+            const float pn = p[j] + (neg_step * mi) * __builtin_amdgcn_rcpf(denom);
             am[R0 + j] = mi;
             av[R0 + j] = vi;
+            if ((j + 1) * FT_THREADS <= P || t + j * FT_THREADS < (unsigned)P) base[off[j]] = pn;
         }
     }
 }
@@ -506,7 +602,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     for (int i = tid; i < C::LDS_FLOATS; i += FT_THREADS) lds[i] = 0.f;
     __syncthreads();
     float am[C::NADAM], av[C::NADAM];
-    if (C::HAS_U) {
+    if constexpr (C::HAS_U) {
         state_load<C, L_L0>(gP, gM, gV, arena, am, av);
         state_load<C, L_L1>(gP, gM, gV, arena, am, av);
         state_load<C, L_L2>(gP, gM, gV, arena, am, av);
@@ -527,7 +623,11 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     load_xu<C>(xu, idxp[tid >> 3], xd, ud);
     float neg_step = 0.f, inv_bc2 = 1.f;       // of the previous step (its last layer's Adam runs in P0)
 
+#ifdef FT_ABL_NOADAM           // timing experiment only
+#define ADAM(L_, STAGE_) ((void)0)
+#else
 #define ADAM(L_, STAGE_) adam_layer<C, L_>(arena, STAGE_, am, av, w1, b2, w2, neg_step, inv_bc2, aeps)
+#endif
 
     for (int s = 0; s < A.n_steps; ++s) {
         // wave id / lane re-derived per step behind an optimisation barrier so the address arithmetic of ~20
@@ -541,7 +641,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         STAMP(0);
         // ---- P0: Adam of the previous step's last layer; [x | u | 1] (prefetched) -> T3; eps -> sZ
         if (s > 0) {
-            if (C::HAS_U) ADAM(L_L0, T0); else ADAM(L_V0, T1);
+            if constexpr (C::HAS_U) ADAM(L_L0, T0); else ADAM(L_V0, T1);
         }
         neg_step = A.neg_step[s];
         inv_bc2 = A.inv_bc2_sqrt[s];
@@ -592,7 +692,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         // ---- F3: heads g -> sG (waves 0-3), v = exp(logv) -> sV (waves 4-7); prior layer 1: h1l -> T0
         if (w < 4) fwd_head<C, DL, false>(T2, arena + C::off_of(L_G2), sG, rt);
         else fwd_head<C, DL, true>(T4, arena + C::off_of(L_V2), sV, rt);
-        if (C::HAS_U) {
+        if constexpr (C::HAS_U) {
             const float* const W[1] = {arena + C::off_of(L_L0)};
             float* const out[1] = {T0};
             f32x4 keep[1][2];
@@ -601,7 +701,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         }
         lds_barrier(); STAMP(4);
         // ---- F4: prior layer 2: h2l -> T1; reparameterisation z = g + eps * sqrt(v) -> sZ (nets.py:301-304)
-        if (C::HAS_U) {
+        if constexpr (C::HAS_U) {
             const float* const W[1] = {arena + C::off_of(L_L1)};
             float* const out[1] = {T1};
             f32x4 keep[1][2];
@@ -619,7 +719,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         }
         lds_barrier(); STAMP(5);
         // ---- F5: prior head l = exp(logl) -> sL (waves 0-3); decoder layer 1: h1f -> T2
-        if (C::HAS_U && w < 4) fwd_head<C, DL, true>(T1, arena + C::off_of(L_L2), sL, rt);
+        if constexpr (C::HAS_U) if (w < 4) fwd_head<C, DL, true>(T1, arena + C::off_of(L_L2), sL, rt);
         {
             const float* const W[1] = {arena + C::off_of(L_F0)};
             float* const out[1] = {T2};
@@ -635,21 +735,31 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             fwd_hidden<C, 1, KS_H>(T2, ST, W, out, slope, w, keep);
         }
         lds_barrier(); STAMP(7);
-        // ---- D3: decoder head f, log p(x|z) and dLoss/df -> sO (waves 0-3)
+        // ---- D3: decoder head f, log p(x|z) and dLoss/df -> sO (waves 0-3); latent log-densities
+        //          log q(z|x,u), log p(z|u) (nets.py:306-314) on waves 4-7
         float lsum = 0.f;
         if (w < 4) {
             const f32x4 acc = mm_fwd1<KS_H>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F2) + min(c, DD - 1) * KS_H, q);
-            const float dv = A.decoder_var, logdv = logf(A.decoder_var);
+            const float inv_dv = 1.f / A.decoder_var, logdv = logf(A.decoder_var);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * rt + 4 * q + r;
                 float dout = 0.f;
                 if (c < DD) {
                     const float df = T3[row * ST + c] - acc[r];             // x - f
-                    lsum += A.a * (-0.5f * (LOG2PI_F + logdv + df * df / dv));
-                    dout = -A.a * wB * df / dv;
+                    lsum += A.a * (-0.5f * (LOG2PI_F + logdv + df * df * inv_dv));
+                    dout = -A.a * wB * df * inv_dv;
                 }
                 if (c < SS) sO[row * SS + c] = dout;
+            }
+        } else {
+            for (int e = tid - FT_THREADS / 2; e < FT_B * DL; e += FT_THREADS / 2) {
+                const int b = e / DL, k = e - b * DL, i = b * SS + k;
+                const float zz = sZ[i], vv = sV[i], dq = zz - sG[i];
+                const float lqc = -0.5f * (LOG2PI_F + flog(vv) + dq * dq * __builtin_amdgcn_rcpf(vv));
+                float lp = -0.5f * (LOG2PI_F + zz * zz);
+                if constexpr (C::HAS_U) { const float ll = sL[i]; lp = -0.5f * (LOG2PI_F + flog(ll) + zz * zz * __builtin_amdgcn_rcpf(ll)); }
+                lsum += A.d * lp - A.b * lqc;
             }
         }
         lds_barrier(); STAMP(8);
@@ -664,35 +774,34 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         ADAM(L_F2, T0 + C::STG_F2);
         lds_barrier(); STAMP(10);
         // ---- BF1: dLoss/dz -> sD (waves 0-3); layer-1 gradient -> stF0 (waves 4-7); Adam(F1)
-        if (w < 4) {
-            const f32x4 acc = mm_dgrad1<KS_H, H, KS_F0>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F0) + min(c, KS_F0 - 1), q);
+        stagger(w, LAMBDA {
+            if (w < 4) {
+                const f32x4 acc = mm_dgrad1<KS_H, H, KS_F0>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F0) + min(c, KS_F0 - 1), q);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (c < DL) sD[(16 * rt + 4 * q + r) * SS + c] = acc[r];
-        } else {
-            wgrad_tile<C, H, KS_F0, DL>(T4, ST, sZ, SS, stF0, w - 4, 0);
-        }
-        ADAM(L_F1, T0);
+                for (int r = 0; r < 4; ++r)
+                    if (c < DL) sD[(16 * rt + 4 * q + r) * SS + c] = acc[r];
+            } else {
+                wgrad_tile<C, H, KS_F0, DL>(T4, ST, sZ, SS, stF0, w - 4, 0);
+            }
+        }, LAMBDA { ADAM(L_F1, T0); });
         lds_barrier(); STAMP(11);
-        // ---- E: latent log-densities (nets.py:306-314) and head deltas in place (SURVEY §8 a-bwd):
-        //         sG <- dg, sV <- dlogv, sL <- dlogl; Adam(F0); h2g -> T2, h1g -> T4
+        // ---- E: head deltas in place (SURVEY §8 a-bwd): sG <- dg, sV <- dlogv, sL <- dlogl; Adam(F0);
+        //         h2g -> T2, h1g -> T4 (operands of the encoder's weight gradients)
         for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
             const int b = e / SS, k = e - b * SS;
             float dg = 0.f, dv = 0.f, dl = 0.f;
             if (k < DL) {
-                const float zz = sZ[e], gg = sG[e], vv = sV[e], ll = C::HAS_U ? sL[e] : 1.f;
-                const float dq = zz - gg;
-                const float rr = dq / vv;
-                const float lqc = -0.5f * (LOG2PI_F + logf(vv) + dq * rr);
-                const float lp = -0.5f * (LOG2PI_F + logf(ll) + zz * zz / ll);
-                lsum += A.d * lp - A.b * lqc;
-                const float Gz = sD[b * SS + k] - wB * (A.b * rr - A.d * zz / ll);
+                const float zz = sZ[e], vv = sV[e];
+                const float dq = zz - sG[e];
+                const float rr = dq * __builtin_amdgcn_rcpf(vv);
+                const float zl = C::HAS_U ? zz * __builtin_amdgcn_rcpf(sL[e]) : zz;
+                const float Gz = sD[e] - wB * (A.b * rr - A.d * zl);
                 dg = wB * A.b * rr + Gz;
                 dv = -wB * A.b * 0.5f * (1.f - dq * rr) + Gz * 0.5f * dq;
-                dl = wB * A.d * 0.5f * (1.f - zz * zz / ll);
+                dl = wB * A.d * 0.5f * (1.f - zz * zl);
             }
             sG[e] = dg; sV[e] = dv;
-            if (C::HAS_U) sL[e] = dl;
+            if constexpr (C::HAS_U) sL[e] = dl;
         }
         ADAM(L_F0, stF0);
         restore_tile<C>(k2g, T2, w);
@@ -710,64 +819,61 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             const float t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
             A.loss_out[(size_t)model * A.n_steps_total + A.step_begin + s] = -t * wB;
         }
-        dgrad_hidden<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), T2, T0, slope, w);
+        dgrad_hidden_reg<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), k2g, T0, slope, w);
         if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
         lds_barrier(); STAMP(13);
         // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
-        dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), T4, T2, slope, w);
+        dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), k1g, T2, slope, w);
         wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w);
         ADAM(L_G2, sZ);
         lds_barrier(); STAMP(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
-        wgrad_pair<C, H, KS_E0, C::KIN>(T2, ST, T3, ST, T0, w);
-        ADAM(L_G1, T1);
-        restore_tile<C>(k2v, T4, w);
+        stagger(w, LAMBDA { wgrad_pair<C, H, KS_E0, C::KIN>(T2, ST, T3, ST, T0, w); },
+                LAMBDA { ADAM(L_G1, T1); restore_tile<C>(k2v, T4, w); });
         lds_barrier(); STAMP(15);
 
         // ---- V3: d2v -> T1; head gradient -> sZ; Adam(G0); h1v -> T2
-        dgrad_hidden<C, SS, DL, KS_H, H>(sV, SS, arena + C::off_of(L_V2), T4, T1, slope, w);
-        if (w < 4) wgrad_tile<C, DL, KS_H, H>(sV, SS, T4, ST, sZ, 0, w);
-        ADAM(L_G0, T0);
-        restore_tile<C>(k1v, T2, w);
+        stagger(w, LAMBDA {
+                    dgrad_hidden_reg<C, SS, DL, KS_H, H>(sV, SS, arena + C::off_of(L_V2), k2v, T1, slope, w);
+                    if (w < 4) wgrad_tile<C, DL, KS_H, H>(sV, SS, T4, ST, sZ, 0, w);
+                }, LAMBDA { ADAM(L_G0, T0); restore_tile<C>(k1v, T2, w); });
         lds_barrier(); STAMP(16);
         // ---- V2: d1v -> T4; layer-2 gradient -> T0; Adam(V2)
-        dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), T2, T4, slope, w);
+        dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), k1v, T4, slope, w);
         wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w);
         ADAM(L_V2, sZ);
         lds_barrier(); STAMP(17);
         // ---- V1: layer-1 gradient -> T1; Adam(V1); h2l -> T2
-        wgrad_pair<C, H, KS_E0, C::KIN>(T4, ST, T3, ST, T1, w);
-        ADAM(L_V1, T0);
-        if (C::HAS_U) restore_tile<C>(k2l, T2, w);
+        stagger(w, LAMBDA { wgrad_pair<C, H, KS_E0, C::KIN>(T4, ST, T3, ST, T1, w); },
+                LAMBDA { ADAM(L_V1, T0); if constexpr (C::HAS_U) restore_tile<C>(k2l, T2, w); });
         lds_barrier(); STAMP(18);
 
-        if (C::HAS_U) {
+        if constexpr (C::HAS_U) {
             // ---- L3: d2l -> T0; head gradient -> sZ; Adam(V0); h1l -> T4
-            dgrad_hidden<C, SS, DL, KS_H, H>(sL, SS, arena + C::off_of(L_L2), T2, T0, slope, w);
-            if (w < 4) wgrad_tile<C, DL, KS_H, H>(sL, SS, T2, ST, sZ, 0, w);
-            ADAM(L_V0, T1);
-            restore_tile<C>(k1l, T4, w);
+            stagger(w, LAMBDA {
+                        dgrad_hidden_reg<C, SS, DL, KS_H, H>(sL, SS, arena + C::off_of(L_L2), k2l, T0, slope, w);
+                        if (w < 4) wgrad_tile<C, DL, KS_H, H>(sL, SS, T2, ST, sZ, 0, w);
+                    }, LAMBDA { ADAM(L_V0, T1); restore_tile<C>(k1l, T4, w); });
             lds_barrier(); STAMP(19);
             // ---- L2: d1l -> T2; layer-2 gradient -> T1; Adam(L2)
-            dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), T4, T2, slope, w);
+            dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), k1l, T2, slope, w);
             wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w);
             ADAM(L_L2, sZ);
             lds_barrier(); STAMP(20);
             // ---- L1: layer-1 gradient -> T0; Adam(L1)
-            wgrad_pair<C, H, KS_L0, M>(T2, ST, T3 + C::UOFF, ST, T0, w);
-            ADAM(L_L1, T1);
+            stagger(w, LAMBDA { wgrad_pair<C, H, KS_L0, M>(T2, ST, T3 + C::UOFF, ST, T0, w); }, LAMBDA { ADAM(L_L1, T1); });
             lds_barrier(); STAMP(21);
         }
     }
     // Adam of the last step's last layer
     if (A.n_steps > 0) {
-        if (C::HAS_U) ADAM(L_L0, T0); else ADAM(L_V0, T1);
+        if constexpr (C::HAS_U) ADAM(L_L0, T0); else ADAM(L_V0, T1);
     }
 #undef ADAM
     __syncthreads();
 
     // ---- write state back
-    if (C::HAS_U) {
+    if constexpr (C::HAS_U) {
         state_store<C, L_L0>(gP, gM, gV, arena, am, av);
         state_store<C, L_L1>(gP, gM, gV, arena, am, av);
         state_store<C, L_L2>(gP, gM, gV, arena, am, av);
