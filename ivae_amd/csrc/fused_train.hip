@@ -407,7 +407,7 @@ __device__ __forceinline__ void dgrad_hidden_reg(const float* dY, int sy, const 
 
 // Weight gradient of a layer with > 16 input columns: stage[n][k] = sum_b dY[b][n] X[b][k] for k <= KB (k == KB
 // is the bias gradient: X carries a constant-1 column there), 0 beyond.  Wave w: rows 16*(w&3).., column half w>>2.
-template <class C, int N, int KS, int KB>
+template <class C, int N, int KS, int KB, bool ROWGUARD = false>
 __device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float* X, int sx, float* stage, int w) {
     const int lane = opaque_lane();
     const int c = lane & 15, q = lane >> 4;
@@ -416,8 +416,8 @@ __device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float*
     mm_wgrad(dY + min(16 * nt + c, sy - 1), sy, X + min(col0, KS - 2), sx, q, acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int n = 16 * nt + 4 * q + r;       // rows >= N land in the unused tail of the (64-row) stage tile
-        if (col0 < KS) st2(stage + n * KS + col0, col0 <= KB ? acc[0][r] : 0.f, col0 + 1 <= KB ? acc[1][r] : 0.f);
+        const int n = 16 * nt + 4 * q + r;       // rows >= N land in the tail of the (64-row) stage tile unless guarded
+        if (col0 < KS && (!ROWGUARD || n < N)) st2(stage + n * KS + col0, col0 <= KB ? acc[0][r] : 0.f, col0 + 1 <= KB ? acc[1][r] : 0.f);
     }
 }
 
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         lds_barrier(); STAMP(9);
         // ---- BF2: d1f -> T4; layer-2 gradient -> T0; Adam(F2)
         dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_F1), T2, T4, slope, w);
-        wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w);
+        wgrad_pair<C, H, KS_H, H, true>(T1, ST, T2, ST, T0, w);     // guarded: the tile's tail holds the F2 stage
         ADAM(L_F2, T0 + C::STG_F2);
         lds_barrier(); STAMP(10);
         // ---- BF1: dLoss/dz -> sD (waves 0-3); layer-1 gradient -> stF0 (waves 4-7); Adam(F1)
