@@ -618,6 +618,11 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     state_load<C, L_V2>(gP, gM, gV, arena, am, av);
     __syncthreads();
 
+#if defined(FT_PRIO_X)
+    if (w_init < 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(FT_PRIO_Y)
+    if (w_init >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const float w1 = A.w1, b2 = A.beta2, w2 = A.w2, aeps = A.adam_eps;
     float xu[C::NXU];
     load_xu<C>(xu, idxp[tid >> 3], xd, ud);
@@ -769,9 +774,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         if (w < 4) wgrad_tile<C, DD, KS_H, H>(sO, SS, T4, ST, T0 + C::STG_F2, 0, w);
         lds_barrier(); STAMP(9);
         // ---- BF2: d1f -> T4; layer-2 gradient -> T0; Adam(F2)
-        dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_F1), T2, T4, slope, w);
-        wgrad_pair<C, H, KS_H, H, true>(T1, ST, T2, ST, T0, w);     // guarded: the tile's tail holds the F2 stage
-        ADAM(L_F2, T0 + C::STG_F2);
+        stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_F1), T2, T4, slope, w); },
+                LAMBDA { wgrad_pair<C, H, KS_H, H, true>(T1, ST, T2, ST, T0, w);     // guarded: the tile's tail holds the F2 stage
+                         ADAM(L_F2, T0 + C::STG_F2); });
         lds_barrier(); STAMP(10);
         // ---- BF1: dLoss/dz -> sD (waves 0-3); layer-1 gradient -> stF0 (waves 4-7); Adam(F1)
         stagger(w, LAMBDA {
@@ -823,9 +828,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
         lds_barrier(); STAMP(13);
         // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
-        dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), k1g, T2, slope, w);
-        wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w);
-        ADAM(L_G2, sZ);
+        stagger(w, LAMBDA { dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), k1g, T2, slope, w); },
+                LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_G2, sZ); });
         lds_barrier(); STAMP(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
         stagger(w, LAMBDA { wgrad_pair<C, H, KS_E0, C::KIN>(T2, ST, T3, ST, T0, w); },
@@ -839,9 +843,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 }, LAMBDA { ADAM(L_G0, T0); restore_tile<C>(k1v, T2, w); });
         lds_barrier(); STAMP(16);
         // ---- V2: d1v -> T4; layer-2 gradient -> T0; Adam(V2)
-        dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), k1v, T4, slope, w);
-        wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w);
-        ADAM(L_V2, sZ);
+        stagger(w, LAMBDA { dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), k1v, T4, slope, w); },
+                LAMBDA { wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w); ADAM(L_V2, sZ); });
         lds_barrier(); STAMP(17);
         // ---- V1: layer-1 gradient -> T1; Adam(V1); h2l -> T2
         stagger(w, LAMBDA { wgrad_pair<C, H, KS_E0, C::KIN>(T4, ST, T3, ST, T1, w); },
@@ -856,9 +859,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                     }, LAMBDA { ADAM(L_V0, T1); restore_tile<C>(k1l, T4, w); });
             lds_barrier(); STAMP(19);
             // ---- L2: d1l -> T2; layer-2 gradient -> T1; Adam(L2)
-            dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), k1l, T2, slope, w);
-            wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w);
-            ADAM(L_L2, sZ);
+            stagger(w, LAMBDA { dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), k1l, T2, slope, w); },
+                    LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_L2, sZ); });
             lds_barrier(); STAMP(20);
             // ---- L1: layer-1 gradient -> T0; Adam(L1)
             stagger(w, LAMBDA { wgrad_pair<C, H, KS_L0, M>(T2, ST, T3 + C::UOFF, ST, T0, w); }, LAMBDA { ADAM(L_L1, T1); });
