@@ -81,6 +81,59 @@ def test_fused_steps_match_oracle(name, n_steps):
             assert relmax(z[m].cpu().numpy(), zl) < 1e-5
 
 
+@pytest.mark.parametrize("dd,dl,M", [(5, 5, 40), (5, 5, 0)])
+def test_fused_odd_dims_match_oracle(dd, dl, M):
+    """d = 5: u sits behind a hole column of the encoder input tile, heads are 5 wide (the d = 5 end of the
+    BASELINE configs[4] sweep).  No reference fixture at this shape: parity is against the fp64 oracle, which the
+    fixtures pin at other shapes."""
+    from oracle import torch_ref
+    spec = np_ref.Spec(dd, dl, M)
+    names = spec.param_names()
+    shape = ops.ModelShape(dd, dl, M, 50, 3, "lrelu", .1)
+    assert ops.train_steps_supported(shape, 64)
+    n_models, n_steps = 2, 3
+    X, U, idx, eps = make_problem(spec, n_models, n_steps, seed=11)
+    P0s = [{k: v.numpy() for k, v in torch_ref.xavier_params(spec, seed=m).items()} for m in range(n_models)]
+    d = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    params = t(np.stack([flat(P, names) for P in P0s]))
+    m1, v1 = torch.zeros_like(params), torch.zeros_like(params)
+    coef = ops.make_coef(decoder_var=spec.decoder_var, global_batch=64)
+    loss, z = ops.train_steps(shape, coef, params, m1, v1, t(X), t(U) if U is not None else None, t(idx), 0, 1e-2,
+                              eps=t(eps), want_z=True)
+    for m in range(n_models):
+        P, Mo, V, losses, zl = oracle_run(spec, P0s[m], X[m], U[m] if U is not None else None, idx[m], eps[m], 1e-2,
+                                          np_ref.Coef(pairwise=False))
+        got = loss[m].cpu().numpy()
+        assert abs(got[0] - losses[0]) <= 1e-5 * abs(losses[0]), (m, got[0], losses[0])
+        assert np.all(np.abs(got - losses) <= 2e-3 * np.abs(losses)), (m, got, losses)
+        perr = np.abs(params[m].cpu().numpy() - flat(P, names))
+        assert perr.max() < 2e-2 * 1e-2 and perr.mean() < 1e-4, (m, perr.max(), perr.mean())
+        assert relmax(z[m].cpu().numpy(), zl) < 1e-3
+
+
+def test_fused_first_step_moments_odd_dims():
+    """One step at d = 5: exp_avg = 0.1 * grad, so every gradient (hole column included) is checked to 1e-5."""
+    from oracle import torch_ref
+    spec = np_ref.Spec(5, 5, 40)
+    names = spec.param_names()
+    shape = ops.ModelShape(5, 5, 40, 50, 3, "lrelu", .1)
+    X, U, idx, eps = make_problem(spec, 1, 1, seed=12)
+    P0 = {k: v.numpy() for k, v in torch_ref.xavier_params(spec, seed=3).items()}
+    d = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    params = t(flat(P0, names)[None])
+    m1, v1 = torch.zeros_like(params), torch.zeros_like(params)
+    coef = ops.make_coef(decoder_var=spec.decoder_var, global_batch=64)
+    ops.train_steps(shape, coef, params, m1, v1, t(X), t(U), t(idx), 0, 1e-2, eps=t(eps))
+    P, Mo, V, losses, zl = oracle_run(spec, P0, X[0], U[0], idx[0], eps[0], 1e-2, np_ref.Coef(pairwise=False))
+    got, off = m1[0].cpu().numpy(), 0
+    for n in names:
+        k = Mo[n].size
+        assert relmax(got[off:off + k], Mo[n].reshape(-1)) < 1e-5, n
+        off += k
+
+
 def test_fused_continues_from_saved_state_and_chunks():
     """200 steps in one call (internally two launches of <=128) == 120 + 80 steps in two calls."""
     c = Case("ivae_plain_cfg2")
