@@ -1,0 +1,154 @@
+"""Work distribution over the GPUs of one node.  One process per GPU; `torch.distributed`
+supplies the process group ("nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).  The reference has
+no multi-GPU path at all (no collective call site anywhere in it), so everything here is defined by the
+single-GPU semantics it must reproduce:
+
+* packed sweeps (BASELINE configs[4]): independent models are dealt to ranks in contiguous ranges and never
+  communicate on the data path -- `model_range`, `gather_model_results` (one gather of results at the end);
+* data-parallel plain ELBO (configs[3]): the loss is a batch mean (nets.py:475), so each rank runs
+  `ivae_elbo_fwd_bwd` on a row shard with `coef.global_batch` = the global batch (loss and gradients come out
+  pre-scaled by 1/B_global), then ONE all-reduce(sum) of the flat gradient (+ the loss scalar), then the
+  identical fused Adam step on every rank;
+* data-parallel pairwise ELBO (cleanIVAE / cleanVAE / iVAE anneal): T[i,j,k] = log q(z_i | x_j) couples every
+  row with every column of the global batch (nets.py:180-182, 466-469), so between forward and backward the
+  ranks all-gather (g, v), run `ivae_pairwise(rows = local, columns = global)`, and all-reduce the column terms
+  (cg, cv) before the usual gradient all-reduce.
+
+The gradient vector is 80-190 KB: one collective per step, latency-bound; nothing is bucketed or overlapped.
+"""
+import torch
+import torch.distributed as dist
+
+
+def model_range(n_models, rank, world):
+    """Contiguous, balanced [lo, hi) share of `n_models` independent models for `rank`."""
+    if not (0 <= rank < world):
+        raise ValueError("rank {} outside world of {}".format(rank, world))
+    base, rem = divmod(n_models, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def row_range(batch, rank, world):
+    """Contiguous, balanced [lo, hi) row shard of a global batch (same rule as model_range)."""
+    return model_range(batch, rank, world)
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def gather_model_results(local, n_models, group=None):
+    """Concatenate per-model result rows (losses, MCC correlation blocks, ...) of every rank on every rank, in
+    model order.  `local` is (hi - lo, ...) for this rank's model_range; ranges may differ by one model."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    sizes = [model_range(n_models, r, world) for r in range(world)]
+    cap = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
+
+
+class DataParallelELBO:
+    """ELBO forward/backward of ONE model on this rank's row shard of a global batch, with the exchanges that
+    make the result equal to the single-GPU full-batch result.
+
+    `backend` is the module that launches the kernels (`ivae_amd.ops`; tests substitute an oracle-backed double to
+    exercise the exchange logic on CPU ranks).  `stage_on_cpu` moves collective payloads through host memory for
+    process groups that cannot take device tensors (gloo with ROCm tensors)."""
+
+    def __init__(self, shape, decoder_var, group=None, backend=None, stage_on_cpu=False):
+        if backend is None:
+            from . import ops as backend
+        self.be = backend
+        self.shape = shape
+        self.decoder_var = float(decoder_var)
+        self.group = group
+        self.stage = stage_on_cpu
+        self.rank, self.world = _world(group)
+        self.ws = backend.Workspace()
+
+    # -- collectives -----------------------------------------------------------------
+    def _all_reduce(self, t):
+        if self.world == 1:
+            return t
+        if self.stage:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def _all_gather_rows(self, t, global_batch):
+        """(local rows, d) of every rank -> (global_batch, d), rows in rank order (row_range partition)."""
+        if self.world == 1:
+            return t
+        sizes = [row_range(global_batch, r, self.world) for r in range(self.world)]
+        cap = max(hi - lo for lo, hi in sizes)
+        src = t.cpu() if self.stage else t
+        pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
+        pad[:t.shape[0]] = src
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        out = torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
+        return out.to(t.device)
+
+    # -- one step ---------------------------------------------------------------------
+    def fwd_bwd(self, params, x, u, eps, global_batch, a=1., b=1., c=1., d=1., N=1., pairwise=False):
+        """x, u, eps: this rank's rows [row_range(global_batch, rank, world)) of the global batch.
+        Returns (loss of the whole batch, z of the local rows, flat gradient of the whole batch); loss and
+        gradient are identical on every rank."""
+        be, sh = self.be, self.shape
+        lo, hi = row_range(global_batch, self.rank, self.world)
+        if x.shape[0] != hi - lo:
+            raise ValueError("rank {} expects rows [{}, {}) of the global batch, got {} rows".format(
+                self.rank, lo, hi, x.shape[0]))
+        coef = be.make_coef(a, b, c, d, N, self.decoder_var, pairwise, global_batch)
+        if not pairwise:
+            loss, z, grads = be.elbo_fwd_bwd(sh, coef, params, x, u, eps, self.ws)
+        else:
+            Bl, dl = hi - lo, sh.latent_dim
+            z = be.forward(sh, coef, params, x, u, eps, self.ws)
+            g_all = self._all_gather_rows(self.ws.view('g', Bl, dl), global_batch)
+            v_all = self._all_gather_rows(self.ws.view('v', Bl, dl), global_batch)
+            pw = be.pairwise(coef, z, g_all.contiguous(), v_all.contiguous())
+            cg, cv = self._all_reduce(pw['cg']), self._all_reduce(pw['cv'])
+            for name in ('lq', 'lqi', 'lse_s'):
+                self.ws.view(name, Bl).copy_(pw[name])
+            self.ws.view('lse_k', Bl, dl).copy_(pw['lse_k'])
+            self.ws.view('rz', Bl, dl).copy_(pw['rz'])
+            self.ws.view('cg', Bl, dl).copy_(cg[lo:hi])
+            self.ws.view('cv', Bl, dl).copy_(cv[lo:hi])
+            loss, grads = be.backward(sh, coef, params, x, u, eps, self.ws)
+        self._all_reduce(grads)
+        self._all_reduce(loss)
+        return loss, z, grads
+
+
+class DataParallelTrainer:
+    """zero_grad -> elbo -> backward -> Adam.step (runners/ivae.py:75-91, wrappers.py:64-70) for one model whose
+    batch is split by rows over the ranks.  Parameters and Adam moments are replicated; every rank applies the
+    same update to the same all-reduced gradient, so replicas stay bit-identical without a broadcast."""
+
+    def __init__(self, shape, params, decoder_var=.01, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None,
+                 backend=None, stage_on_cpu=False):
+        self.dp = DataParallelELBO(shape, decoder_var, group, backend, stage_on_cpu)
+        self.params = params
+        self.exp_avg = torch.zeros_like(params)
+        self.exp_avg_sq = torch.zeros_like(params)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.t = 0
+
+    def step(self, x, u, eps, global_batch, **coef):
+        loss, z, grads = self.dp.fwd_bwd(self.params, x, u, eps, global_batch, **coef)
+        self.t += 1
+        self.dp.be.adam_step(self.params.view(-1), self.exp_avg.view(-1), self.exp_avg_sq.view(-1), grads.view(-1),
+                             self.lr, self.t, self.betas[0], self.betas[1], self.eps)
+        return loss, z

@@ -144,11 +144,16 @@ def logsumexp(t, axis):
 
 
 # --------------------------------------------------------------------- forward
-def elbo_forward(P, x, u, eps, spec, coef, dtype=np.float32):
+def elbo_forward(P, x, u, eps, spec, coef, dtype=np.float32, global_batch=None, pair_cols=None):
     """Forward of models/nets.py:450-475 (iVAE), 587-599 (VAE), 165-185
     (cleanIVAE), 224-243 (cleanVAE).  Returns a dict with every intermediate;
     ``loss`` is the quantity to MINIMISE (family A returns it directly, family
-    B returns its negation)."""
+    B returns its negation).
+
+    Row-shard form (the reference has no multi-GPU path): with ``global_batch`` = Bg the
+    rows given are a shard of a batch of Bg and ``loss`` = -sum(row)/Bg, so shard losses add up to the
+    full-batch loss; ``pair_cols`` = (g_all, v_all) are the encoder outputs of the WHOLE batch, the
+    columns j of T[i,j,k] (nets.py:180,466)."""
     dt = np.dtype(dtype).type
     P = {k: np.asarray(v, dtype) for k, v in P.items()}
     x = np.asarray(x, dtype)
@@ -178,9 +183,11 @@ def elbo_forward(P, x, u, eps, spec, coef, dtype=np.float32):
     out.update(g=g, v=v, logv=logv, l=l, logl=logl, z=z, f=f, lpx=lpx, lqc=lqc, lp=lp,
                eps=eps, xu=xu, caches=caches)
     a, b, c, d = (dt(t) for t in (coef.a, coef.b, coef.c, coef.d))
+    Bg = B if global_batch is None else int(global_batch)
     if coef.pairwise:
-        T = log_normal(z[:, None, :], g[None, :, :], v[None, :, :], log2pi)   # nets.py:180,466
-        logMN = dt(np.log(B * coef.N))
+        gc, vc = (g, v) if pair_cols is None else (np.asarray(pair_cols[0], dtype), np.asarray(pair_cols[1], dtype))
+        T = log_normal(z[:, None, :], gc[None, :, :], vc[None, :, :], log2pi)   # nets.py:180,466
+        logMN = dt(np.log(Bg * coef.N))
         S = T.sum(-1)
         lq = logsumexp(S, 1) - logMN                                          # nets.py:181,468
         lqi = (logsumexp(T, 1) - logMN).sum(-1)                               # nets.py:182,469
@@ -189,19 +196,37 @@ def elbo_forward(P, x, u, eps, spec, coef, dtype=np.float32):
     else:
         row = a * lpx - b * lqc + d * lp                                      # nets.py:475,599
     out["row"] = row
-    out["loss"] = -row.mean(dtype=dtype)
+    out["loss"] = -row.mean(dtype=dtype) if global_batch is None else -row.sum(dtype=dtype) / dt(Bg)
     return out
 
 
 # -------------------------------------------------------------------- backward
-def elbo_backward(P, x, u, fw, spec, coef, dtype=np.float32):
+def pairwise_terms(z, g_cols, v_cols, coef, global_batch, dtype=np.float64):
+    """Row statistics and gradient terms of T[i,j,k] = log N(z_ik; g_jk, v_jk) (nets.py:180-182, 466-469) for
+    rows z of one shard against the columns of the whole batch: what ``ivae_pairwise`` returns."""
+    dt = np.dtype(dtype).type
+    z, gc, vc = (np.asarray(t, dtype) for t in (z, g_cols, v_cols))
+    T = log_normal(z[:, None, :], gc[None], vc[None], dt(np.log(2 * np.pi)))
+    S = T.sum(-1)
+    lse_s, lse_k = logsumexp(S, 1), logsumexp(T, 1)
+    logMN = dt(np.log(global_batch * coef.N))
+    Wt = (coef.b - coef.c) * np.exp(S - lse_s[:, None])[:, :, None] + (coef.c - coef.d) * np.exp(T - lse_k[:, None, :])
+    diff = z[:, None, :] - gc[None]
+    rij = diff / vc[None]
+    return dict(lq=lse_s - logMN, lqi=(lse_k - logMN).sum(-1), lse_s=lse_s, lse_k=lse_k, rz=(Wt * -rij).sum(1),
+                cg=(Wt * rij).sum(0), cv=(Wt * -0.5 * (1 - diff * rij)).sum(0))
+
+
+def elbo_backward(P, x, u, fw, spec, coef, dtype=np.float32, global_batch=None, pair=None):
     """Analytic gradient of ``loss`` w.r.t. every parameter (what
-    ``loss.backward()`` produces at runners/ivae.py:82, wrappers.py:69)."""
+    ``loss.backward()`` produces at runners/ivae.py:82, wrappers.py:69).
+    Row-shard form: ``global_batch`` as in elbo_forward; ``pair`` = dict(rz, cg, cv) holds the pairwise
+    gradient terms of THESE rows with cg/cv already summed over every shard's rows."""
     dt = np.dtype(dtype).type
     P = {k: np.asarray(v, dtype) for k, v in P.items()}
     x = np.asarray(x, dtype)
     B = x.shape[0]
-    w = dt(1.0) / dt(B)
+    w = dt(1.0) / dt(B if global_batch is None else global_batch)
     a, b, c, d = (dt(t) for t in (coef.a, coef.b, coef.c, coef.d))
     g, v, l, z, f, eps = fw["g"], fw["v"], fw["l"], fw["z"], fw["f"], fw["eps"]
     caches = fw["caches"]
@@ -216,7 +241,11 @@ def elbo_backward(P, x, u, fw, spec, coef, dtype=np.float32):
     Gz = dz + (-w) * (b * r - d * z / l)
     dg = (-w) * (-b * r)
     dlogv = (-w) * (b * half * (1 - (z - g) ** 2 / v))
-    if coef.pairwise:
+    if coef.pairwise and pair is not None:
+        Gz = Gz + (-w) * np.asarray(pair["rz"], dtype)
+        dg = dg + (-w) * np.asarray(pair["cg"], dtype)
+        dlogv = dlogv + (-w) * np.asarray(pair["cv"], dtype)
+    elif coef.pairwise:
         T = fw["T"]
         S = T.sum(-1)
         Pm = np.exp(S - logsumexp(S, 1)[:, None])                  # softmax_j sum_k T

@@ -1,0 +1,76 @@
+"""Data-parallel path on the real kernels: two ranks (two processes sharing cuda:0, gloo process group with host
+staging -- RCCL needs one device per rank and the test box has one GPU) must reproduce the single-process
+full-batch result of `ivae_elbo_fwd_bwd` on reference fixtures, for the plain ELBO (configs[3] shape class) and
+for the pairwise ELBO whose columns cross ranks (all-gather of (g, v), all-reduce of (cg, cv))."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.util import Case, relmax
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _flat(group, names):
+    return np.concatenate([group[n].reshape(-1) for n in names])
+
+
+def _worker(rank, world, port, name, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ivae_amd import ops
+        from ivae_amd.dist import DataParallelELBO, row_range
+        c = Case(name)
+        s = c.spec
+        shape = ops.ModelShape(s.data_dim, s.latent_dim, s.aux_dim, s.hidden_dim, s.n_layers, s.activation, s.slope)
+        d = torch.device("cuda:0")
+        x, u, eps = c.inputs()
+        B = x.shape[0]
+        lo, hi = row_range(B, rank, world)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+        co = c.coef(0)
+        dp = DataParallelELBO(shape, s.decoder_var, stage_on_cpu=True)
+        loss, z, grads = dp.fwd_bwd(t(_flat(c.params, s.param_names())), t(x[lo:hi]), t(u[lo:hi]) if s.aux_dim else None,
+                                    t(eps[lo:hi]), B, a=co.a, b=co.b, c=co.c, d=co.d, N=co.N, pairwise=co.pairwise)
+        torch.cuda.synchronize()
+        out.put((rank, float(loss[0]), z.cpu().numpy(), grads.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["ivae_plain_cfg4s", "cleanivae_lrelu_b70", "cleanvae_btcvae_b200"])
+def test_two_ranks_match_full_batch_fixture(name):
+    c = Case(name)
+    names = c.spec.param_names()
+    ctx = mp.get_context("spawn")
+    out = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get() for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, l0, z0, g0), (_, l1, z1, g1) = res
+    assert l0 == l1 and np.array_equal(g0, g1)                       # every rank holds the same reduced result
+    # vs the reference fixture (full batch on one device), north_star tolerance 1e-5
+    assert abs(l0 - c.loss()) <= 1e-5 * abs(c.loss())
+    assert relmax(np.concatenate([z0, z1]), c.z["z"]) < 1e-5
+    off = 0
+    for n in names:
+        ref = c.grads[n]
+        assert relmax(g0[off:off + ref.size].reshape(ref.shape), ref) < 1e-5, n
+        off += ref.size
