@@ -135,7 +135,9 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
  *   u_data (n_models, n_data, aux_dim) or NULL;  batch_idx (n_models, n_steps, 64) int32 rows;
  *   eps (n_models, n_steps, 64, latent_dim) or NULL -> in-kernel Philox4x32-10 + Box-Muller (seed);
  *   step0 = Adam steps already taken;  loss_out (n_models, n_steps);
- *   z_out (n_models, 64, latent_dim) of the LAST step, or NULL.
+ *   z_out (n_models, 64, latent_dim) of the LAST step, or NULL;
+ *   z_steps (n_models, n_steps, 64, latent_dim) of EVERY step (the per-step z_est that
+ *   models/wrappers.py:75 scores against the true sources), or NULL.
  * coef: a, b, d, decoder_var are used (pairwise must be 0, global_batch 64). */
 int ivae_train_steps_supported(const IvaeDims* dims);
 int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef,
@@ -144,7 +146,7 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef,
                      const int32_t* batch_idx, const float* eps, uint64_t seed,
                      int32_t n_steps, int64_t step0,
                      double lr, double beta1, double beta2, double adam_eps,
-                     float* loss_out, float* z_out, void* stream);
+                     float* loss_out, float* z_out, float* z_steps, void* stream);
 
 /* ---- Adam ---------------------------------------------------------------------------
  * Replaces optimizer.step() of torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8)

@@ -62,7 +62,7 @@ def lib():
     L.ivae_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, f64, f64, f64, f64, C.c_int64, vp]
     L.ivae_train_steps_supported.argtypes = [pd]
     L.ivae_train_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_uint64, C.c_int32, C.c_int64,
-                                   f64, f64, f64, f64, vp, vp, vp]
+                                   f64, f64, f64, f64, vp, vp, vp, vp]
     L.ivae_corr_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_size_t)]
     L.ivae_corr.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_size_t, vp]
     L.ivae_last_hip_error.restype = C.c_char_p

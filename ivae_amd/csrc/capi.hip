@@ -127,7 +127,7 @@ int ivae_train_steps_supported(const IvaeDims* d) {
 int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
                      const float* x_data, const float* u_data, int64_t n_data, const int32_t* batch_idx,
                      const float* eps, uint64_t seed, int32_t n_steps, int64_t step0, double lr, double beta1,
-                     double beta2, double adam_eps, float* loss_out, float* z_out, void* stream) {
+                     double beta2, double adam_eps, float* loss_out, float* z_out, float* z_steps, void* stream) {
     int rc = ivae_check_dims(dims);
     if (rc) return rc;
     if ((rc = check_coef(dims, coef))) return rc;
@@ -138,7 +138,7 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, 
     FusedArgs A;
     A.params = params; A.exp_avg = exp_avg; A.exp_avg_sq = exp_avg_sq;
     A.x_data = x_data; A.u_data = u_data; A.batch_idx = batch_idx; A.eps = eps;
-    A.loss_out = loss_out; A.n_data = n_data; A.seed = seed;
+    A.loss_out = loss_out; A.z_steps = z_steps; A.n_data = n_data; A.seed = seed;
     A.a = coef->a; A.b = coef->b; A.d = coef->d; A.decoder_var = coef->decoder_var; A.slope = dims->slope;
     A.w1 = (float)(1.0 - beta1); A.beta2 = (float)beta2; A.w2 = (float)(1.0 - beta2); A.adam_eps = (float)adam_eps;
     A.n_steps_total = n_steps;

@@ -15,6 +15,7 @@ struct FusedArgs {
     const float* eps;         // (n_models, n_steps, 64, latent) or null -> Philox(seed)
     float* loss_out;          // (n_models, n_steps)
     float* z_out;             // (n_models, 64, latent) of the last step, or null
+    float* z_steps;           // (n_models, n_steps, 64, latent) of every step, or null
     int64_t n_data;
     unsigned long long seed;
     int64_t step0;            // Adam steps done before this launch

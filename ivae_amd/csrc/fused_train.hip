@@ -719,6 +719,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             if (k < DL) {
                 zz = sZ[e] * sqrtf(sV[e]) + sG[e];
                 if (A.z_out && s == A.n_steps - 1) A.z_out[((size_t)model * FT_B + b) * DL + k] = zz;
+                if (A.z_steps) A.z_steps[(((size_t)model * A.n_steps_total + A.step_begin + s) * FT_B + b) * DL + k] = zz;
             }
             sZ[e] = zz;
         }

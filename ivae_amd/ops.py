@@ -212,10 +212,11 @@ def train_steps_supported(shape, batch):
 
 
 def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_idx, step0, lr, eps=None, seed=0,
-                beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False):
+                beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False, want_z_steps=False):
     """ivae_train_steps: n_steps fused (elbo -> backward -> Adam) iterations for all packed models.
     params/exp_avg/exp_avg_sq (n_models, P) are updated in place; batch_idx (n_models, n_steps, B) int32.
-    Returns (loss (n_models, n_steps), z of the last step or None)."""
+    Returns (loss (n_models, n_steps), z of the last step or None); with want_z_steps the second value is the
+    (n_models, n_steps, B, latent) z of every step instead."""
     for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (x_data, "x_data")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError(f"{n} must be a contiguous float32 ROCm tensor")
@@ -237,8 +238,11 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
     with torch.cuda.device(dev):
         loss = torch.empty(n_models, n_steps, dtype=torch.float32, device=dev)
         z = torch.empty(n_models, B, shape.latent_dim, dtype=torch.float32, device=dev) if want_z else None
+        zs = (torch.empty(n_models, n_steps, B, shape.latent_dim, dtype=torch.float32, device=dev)
+              if want_z_steps else None)
         check(_lib.lib().ivae_train_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
                                           _ptr(x_data), _ptr(u_data), x_data.shape[1], _ptr(batch_idx), _ptr(eps),
                                           int(seed), n_steps, int(step0), float(lr), float(beta1), float(beta2),
-                                          float(adam_eps), _ptr(loss), _ptr(z), _stream(dev)), "ivae_train_steps")
-    return loss, z
+                                          float(adam_eps), _ptr(loss), _ptr(z), _ptr(zs), _stream(dev)),
+              "ivae_train_steps")
+    return loss, (zs if want_z_steps else z)

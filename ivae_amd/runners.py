@@ -1,0 +1,307 @@
+"""Training loops around the hot path: counterparts of `runners/ivae.py::runner` (family A, what
+`main.py --config *.yaml` runs) and `models/wrappers.py::IVAE_wrapper / VAE_wrapper` (family B, library API).
+
+Same inputs, schedules and return values as the reference loops; what differs is where things live:
+  * the dataset sits in HBM for the whole run and batches are formed on the device from a device-side
+    permutation (DataLoader(shuffle=True[, drop_last=True]) semantics, runners/ivae.py:25, wrappers.py:28);
+  * no per-step host sync: the reference calls `loss.item()` and a host MCC on every step
+    (runners/ivae.py:84-86, wrappers.py:72-76); here losses accumulate on the device, the per-step
+    correlation blocks of the batch MCC are computed by the `ivae_corr` kernel into a device buffer, and the
+    Hungarian assignments of a whole epoch run on the host once the epoch's last launch is queued;
+  * when the model is one the fused persistent kernel covers (plain-ELBO iVAE/VAE, 3 lrelu layers of width 50,
+    batch 64 -- BASELINE configs[1]) the wrappers advance a whole epoch per `ivae_train_steps` launch chain
+    with parameters in LDS; any other shape takes the generic kernels through the drop-in modules.
+Shuffling and noise come from torch's device generators, so trajectories match the reference statistically
+(same distribution of permutations and of eps), not draw for draw; tests/test_gpu_e2e.py replays recorded
+reference permutations and eps through the same kernels for the draw-for-draw check.
+"""
+import time
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+from torch import optim
+
+from . import ops
+from .data import CustomSyntheticDataset, SyntheticDataset
+from .mcc import corr_matrix_gpu, mean_corr_coef as mcc
+from .nets import VAE, cleanIVAE, cleanVAE, iVAE
+from .optim import FusedAdam
+from .runlog import Logger, checkpoint
+
+
+class _ReduceLROnPlateau(optim.lr_scheduler.ReduceLROnPlateau):
+    """The reference passes verbose=True (runners/ivae.py:39, wrappers.py:45), which current torch rejects; keep
+    the behaviour (announce reductions) without the argument."""
+
+    def step(self, metrics, *a, **kw):
+        before = [g['lr'] for g in self.optimizer.param_groups]
+        super().step(metrics, *a, **kw)
+        for i, (b, g) in enumerate(zip(before, self.optimizer.param_groups)):
+            if g['lr'] != b:
+                print('reducing learning rate of group {} to {:.4e}.'.format(i, g['lr']))
+
+
+def _epoch_batches(n, batch_size, drop_last, device, generator):
+    perm = torch.randperm(n, device=device, generator=generator)
+    stop = (n // batch_size) * batch_size if drop_last else n
+    return [perm[i:i + batch_size] for i in range(0, stop, batch_size)]
+
+
+def _assignment_scores(cc_abs):
+    """Mean matched |correlation| per block (metrics/mcc.py:333-335); 0 where the block is not finite, like the
+    bare `except: perf = 0` of runners/ivae.py:85-88."""
+    out = []
+    for cc in cc_abs:
+        out.append(float(cc[linear_sum_assignment(-1 * cc)].mean()) if np.isfinite(cc).all() else 0.)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ family A
+def runner(args, config):
+    """runners/ivae.py:13-128.  `args`: data_path, seed, n_sims.  `config`: the yaml keys of configs/*.yaml plus
+    `device`.  Returns (perfs, loss_hists, perf_hists)."""
+    st = time.time()
+    device = torch.device(config.device)
+    print('Executing script on: {}\n'.format(device))
+    if config.gamma > 0:
+        raise NotImplementedError('FactorVAE discriminator branch (gamma > 0) is outside the fused hot path; every '
+                                  'shipped config has gamma: 0')
+    dset = SyntheticDataset(args.data_path, config.nps, config.ns, config.dl, config.dd, config.nl, config.s, config.p,
+                            config.act, uncentered=config.uncentered, noisy=config.noisy, double=False)
+    d_data, d_latent, d_aux = dset.get_dims()
+    X, U, S = dset.x.to(device), dset.u.to(device), dset.s.to(device)
+    N, B = len(dset), config.batch_size
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(torch.initial_seed()) % (2 ** 63))
+
+    perfs, loss_hists, perf_hists = [], [], []
+    for seed in range(args.seed, args.seed + args.n_sims):
+        if config.ica:
+            model = cleanIVAE(data_dim=d_data, latent_dim=d_latent, aux_dim=d_aux, hidden_dim=config.hidden_dim,
+                              n_layers=config.n_layers, activation=config.activation, slope=.1).to(device)
+        else:
+            model = cleanVAE(data_dim=d_data, latent_dim=d_latent, hidden_dim=config.hidden_dim,
+                             n_layers=config.n_layers, activation=config.activation, slope=.1).to(device)
+        optimizer = FusedAdam(model.parameters(), lr=config.lr)
+        scheduler = _ReduceLROnPlateau(optimizer, factor=0.1, patience=0)
+
+        loss_hist, perf_hist = [], []
+        for epoch in range(1, config.epochs + 1):
+            model.train()
+            a, b, c, d = config.a, config.b, config.c, config.d
+            if config.anneal:                                     # runners/ivae.py:51-60
+                c = 0
+                if epoch > config.epochs / 1.6:
+                    a, b, c, d = 2 * config.a, 1, 1, 1
+            batches = _epoch_batches(N, B, True, device, gen)
+            loss_sum = torch.zeros((), device=device)
+            cc = torch.empty(len(batches), d_latent, d_latent, dtype=torch.float64, device=device)
+            for i, idx in enumerate(batches):
+                x, u, s_true = X[idx], U[idx], S[idx]
+                optimizer.zero_grad()
+                loss, z = model.elbo(x, u, N, a=a, b=b, c=c, d=d)
+                loss.backward()
+                loss_sum += loss.detach()
+                cc[i] = corr_matrix_gpu(s_true, z.detach())
+                optimizer.step()
+            train_loss = float(loss_sum.item()) / len(batches)          # the epoch's one sync
+            train_perf = float(np.mean(_assignment_scores(cc.abs().cpu().numpy())))
+            perf_hist.append(train_perf)
+            loss_hist.append(train_loss)
+            print('==> Epoch {}/{}:\ttrain loss: {:.6f}\ttrain perf: {:.6f}'.format(epoch, config.epochs, train_loss,
+                                                                                    train_perf))
+            if not config.no_scheduler:
+                scheduler.step(train_loss)
+        print('\ntotal runtime: {}'.format(time.time() - st))
+
+        # full-dataset score on a SAMPLE of q(z|x,u), as the reference does (runners/ivae.py:118-123)
+        with torch.no_grad():
+            s = model(X, U)[3] if config.ica else model(X)[3]
+        perfs.append(mcc(S, s))
+        loss_hists.append(loss_hist)
+        perf_hists.append(perf_hist)
+    return perfs, loss_hists, perf_hists
+
+
+# ------------------------------------------------------------------------------------------------ family B
+class _FusedEpochs:
+    """Epoch driver for models the fused kernel covers: full batches go through `ivae_train_steps` (the model's
+    own arena is the kernel's parameter buffer), a ragged final batch through the generic kernels with the same
+    Adam state."""
+
+    def __init__(self, model, lr, seed):
+        self.model = model
+        self.shape = model._shape
+        self.params = model._flat_params()
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.t = 0
+        self.seed = 0 if seed is None else int(seed)
+        self.coef = ops.make_coef(decoder_var=model._decoder_var_f, global_batch=64)
+        self.ws = ops.Workspace()
+        self.group = {'lr': lr, 'betas': (0.9, 0.999), 'eps': 1e-8}
+        self.param_groups = [self.group]           # what ReduceLROnPlateau mutates
+
+    def full_batches(self, X, U, idx):
+        """idx: (k, 64) int32 rows.  -> (loss (k,), z (k, 64, d)) on the device."""
+        loss, z = ops.train_steps(self.shape, self.coef, self.params.view(1, -1), self.m.view(1, -1), self.v.view(1, -1),
+                                  X.unsqueeze(0), None if U is None else U.unsqueeze(0), idx.unsqueeze(0), self.t,
+                                  self.group['lr'], seed=self.seed, want_z_steps=True)
+        self.t += idx.shape[0]
+        return loss[0], z[0]
+
+    def ragged_batch(self, x, u):
+        eps = torch.randn(x.shape[0], self.shape.latent_dim, device=x.device)
+        coef = ops.make_coef(decoder_var=self.model._decoder_var_f, global_batch=x.shape[0])
+        loss, z, grads = ops.elbo_fwd_bwd(self.shape, coef, self.params, x, u, eps, self.ws)
+        self.t += 1
+        ops.adam_step(self.params, self.m, self.v, grads, self.group['lr'], self.t)
+        return loss[0], z
+
+    def as_optimizer(self):
+        """A FusedAdam holding this state, for `checkpoint()` (state_dict layout of torch.optim.Adam)."""
+        opt = FusedAdam(self.model.parameters(), lr=self.group['lr'])
+        off = 0
+        for p in self.model.parameters():
+            n = p.numel()
+            opt.state[p] = {'step': torch.tensor(float(self.t)), 'exp_avg': self.m[off:off + n].view(p.shape),
+                            'exp_avg_sq': self.v[off:off + n].view(p.shape)}
+            off += n
+        return opt
+
+
+def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, log_folder, ckpt_folder, scheduler_tol,
+                    seed, with_u):
+    N = len(dset)
+    X = dset.x.to(device)
+    U = dset.u.to(device) if with_u else None
+    Z = dset.s.to(device) if S is not None else None
+    n_batches = -(-N // batch_size)
+    max_epochs = int(max_iter // n_batches + 1)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(torch.initial_seed()) % (2 ** 63))
+    fused = (not anneal and batch_size == 64 and ops.train_steps_supported(model._shape, 64))
+    if fused:
+        drv = _FusedEpochs(model, lr, seed)
+        # ReduceLROnPlateau wants an Optimizer: a placeholder holds the learning rate the kernel is launched with
+        scheduler = _ReduceLROnPlateau(optim.SGD([torch.zeros(1, requires_grad=True)], lr=lr), factor=0.1,
+                                       patience=scheduler_tol)
+        optimizer = None
+    else:
+        optimizer = FusedAdam(model.parameters(), lr=lr)
+        scheduler = _ReduceLROnPlateau(optimizer, factor=0.1, patience=scheduler_tol)
+
+    logger = Logger(log_dir=log_folder)
+    exp_id = logger.exp_id
+    if log_folder is None:
+        ckpt_folder = None
+    logger.add('elbo')
+    logger.add('perf')
+    ckpt_every = int(max_iter / 5)
+    d = model.latent_dim
+
+    print("Training..")
+    it = 0
+    model.train()
+    while it < max_iter:
+        epoch = it // n_batches + 1
+        batches = _epoch_batches(N, batch_size, False, device, gen)
+        cc = torch.empty(len(batches), d, d, dtype=torch.float64, device=device) if S is not None else None
+        it0 = it
+        if fused:
+            n_full = N // batch_size
+            idx = torch.stack(batches[:n_full]).to(torch.int32)
+            drv.group['lr'] = scheduler.optimizer.param_groups[0]['lr']
+            loss, zs = drv.full_batches(X, U, idx)
+            logger.update('elbo', loss.sum(), weight=n_full)
+            if cc is not None:
+                for i in range(n_full):
+                    cc[i] = corr_matrix_gpu(zs[i], Z[batches[i]])
+            it += n_full
+            for i in range(n_full, len(batches)):
+                l1, z1 = drv.ragged_batch(X[batches[i]], None if U is None else U[batches[i]])
+                logger.update('elbo', l1)
+                if cc is not None:
+                    cc[i] = corr_matrix_gpu(z1, Z[batches[i]])
+                it += 1
+        else:
+            for i, bidx in enumerate(batches):
+                it += 1
+                if anneal:
+                    model.anneal(N, max_iter, it)
+                optimizer.zero_grad()
+                x = X[bidx]
+                elbo, z_est = model.elbo(x, U[bidx]) if with_u else model.elbo(x)
+                elbo.mul(-1).backward()
+                optimizer.step()
+                logger.update('elbo', -elbo.detach())
+                if cc is not None:
+                    cc[i] = corr_matrix_gpu(z_est.detach(), Z[bidx])
+        if cc is not None:
+            for score in _assignment_scores(cc.abs().cpu().numpy()):
+                logger.update('perf', score)
+        logger.log()
+        # checkpoints fall on multiples of max_iter/5 (wrappers.py:78-80); written at the end of the epoch that
+        # crosses one, since a whole epoch is one launch chain here
+        if ckpt_folder is not None and ckpt_every > 0 and it // ckpt_every > it0 // ckpt_every:
+            opt = drv.as_optimizer() if fused else optimizer
+            checkpoint(ckpt_folder, exp_id, (it // ckpt_every) * ckpt_every, model, opt, logger.get_last('elbo'),
+                       logger.get_last('perf'))
+        scheduler.step(logger.get_last('elbo'))
+        if S is not None:
+            print('epoch {}/{} \tloss: {}\tperf: {}'.format(epoch, max_epochs, logger.get_last('elbo'),
+                                                            logger.get_last('perf')))
+        else:
+            print('epoch {}/{} \tloss: {}'.format(epoch, max_epochs, logger.get_last('elbo')))
+
+    with torch.no_grad():
+        decoder_params, encoder_params, z, prior_params = model(X, U) if with_u else model(X)
+    params = {'decoder': decoder_params, 'encoder': encoder_params, 'prior': prior_params}
+    return z, model, params, logger
+
+
+def IVAE_wrapper(X, U, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers=3, hidden_dim=200, lr=1e-2, cuda=True,
+                 activation='lrelu', slope=.1, discrete=False, inference_dim=None,
+                 anneal=False, log_folder=None, ckpt_folder=None, scheduler_tol=3):
+    """models/wrappers.py:14-95.  Returns (z, model, params, logger)."""
+    if discrete:
+        raise NotImplementedError('DiscreteIVAE is outside the fused hot path (SURVEY.md §2 row 15)')
+    if not cuda:
+        raise RuntimeError('ivae_amd has no CPU path: cuda=False is not available')
+    if seed is not None:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+    device = torch.device('cuda')
+    print('training on {}'.format(torch.cuda.get_device_name(device)))
+    dset = CustomSyntheticDataset(X, U, S, 'cpu')
+    data_dim, latent_dim, aux_dim = dset.get_dims()
+    if inference_dim is not None:
+        latent_dim = inference_dim
+    model = iVAE(latent_dim, data_dim, aux_dim, activation=activation, device=device, n_layers=n_layers,
+                 hidden_dim=hidden_dim, slope=slope, anneal=anneal)
+    return _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, log_folder, ckpt_folder,
+                           scheduler_tol, seed, with_u=True)
+
+
+def VAE_wrapper(X, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers=3, hidden_dim=200, lr=1e-2, cuda=True,
+                activation='lrelu', slope=.1, discrete=False, inference_dim=None,
+                log_folder=None, ckpt_folder=None, scheduler_tol=3):
+    """models/wrappers.py:98-176."""
+    if discrete:
+        raise NotImplementedError('DiscreteVAE is outside the fused hot path (SURVEY.md §2 row 15)')
+    if not cuda:
+        raise RuntimeError('ivae_amd has no CPU path: cuda=False is not available')
+    if seed is not None:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+    device = torch.device('cuda')
+    print('training on {}'.format(torch.cuda.get_device_name(device)))
+    dset = CustomSyntheticDataset(X, X, S, 'cpu')
+    data_dim, latent_dim, _ = dset.get_dims()
+    if inference_dim is not None:
+        latent_dim = inference_dim
+    model = VAE(latent_dim, data_dim, activation=activation, device=device, n_layers=n_layers, hidden_dim=hidden_dim,
+                slope=slope)
+    return _train_family_b(model, dset, S, batch_size, max_iter, lr, device, False, log_folder, ckpt_folder,
+                           scheduler_tol, seed, with_u=False)
