@@ -78,3 +78,21 @@ def test_wrappers_generic_path_matches_fused_path_statistically():
     assert z.shape == (2560, 10) and logger.log_dict['elbo'][-1] < logger.log_dict['elbo'][0]
     with pytest.raises(NotImplementedError):
         runners.IVAE_wrapper(X, U, S, discrete=True)
+
+
+def test_command_line_writes_reference_result_file(tmp_path, monkeypatch):
+    """main.py contract: flags, run-directory layout, pickle of (perfs, loss_hists, perf_hists)."""
+    import pickle
+    from ivae_amd.__main__ import main
+    cfg = tmp_path / 'tiny.yaml'
+    cfg.write_text("nps: 100\nns: 8\ndl: 3\ndd: 3\nnl: 3\ns: 1\np: 'gauss'\nact: 'xtanh'\nuncentered: false\nnoisy: false\n"
+                   "n_layers: 3\nhidden_dim: 16\nactivation: 'xtanh'\nica: true\ntcl: false\na: 100\nb: 1\nc: 0\nd: 10\n"
+                   "gamma: 0\nlr: 0.01\nbatch_size: 64\nepochs: 2\nno_scheduler: false\nanneal: false\n")
+    run = tmp_path / 'run'
+    assert main(['--config', str(cfg), '--run', str(run), '--doc', 't', '--n-sims', '1', '--seed', '4']) == 0
+    for sub in ('logs', 'checkpoints', 'datasets'):
+        assert (run / sub / 't').is_dir()
+    assert list((run / 'datasets' / 't').glob('tcl_100_8_3_3_3_1_gauss_xtanh.npz'))
+    with open(run / 'tiny_4_1.p', 'rb') as f:
+        perfs, loss_hists, perf_hists = pickle.load(f)
+    assert len(perfs) == 1 and len(loss_hists[0]) == 2 and len(perf_hists[0]) == 2
