@@ -64,6 +64,20 @@ def flops_per_sample(shape):
     return tot
 
 
+def measured_traffic(kernel, models, steps_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/hbm_traffic.json:
+    FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command); None when this run's launch
+    geometry differs from the profiled one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None
+    if t["kernel"] != kernel or t["models_per_gpu"] != models or t["steps_per_launch"] != steps_per_launch:
+        return None
+    return 1e3 * (t["fetch_kb_per_launch"] + t["write_kb_per_launch"])
+
+
 def cpu_baseline(seconds=10.0):
     """oracle/torch_ref.Trainer (== the reference's loop: elbo -> backward -> Adam.step) timed on the
     host, 1 thread and all allotted threads; the better one is reported."""
@@ -178,7 +192,9 @@ def main():
             "final_mean_loss": round(loss, 3),
             "roofline": {"bound": "mfma", "kernel": tr.dominant_kernel, "achieved": round(achieved, 4),
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 5),
-                         "traffic": None, "avg_launch_us": round(kern_s * 1e6, 2),
+                         "traffic": measured_traffic(tr.dominant_kernel, M, steps_per_launch) if fused else None,
+                         "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/hbm_traffic.json)",
+                         "avg_launch_us": round(kern_s * 1e6, 2),
                          "steps_per_launch": steps_per_launch, "algorithmic_flops_per_launch": algo_flops},
         }
         if world == 1 and not args.no_cpu_baseline:
