@@ -91,7 +91,8 @@ struct FCfg {
     static constexpr int STG_F2 = H * KS_H;                         // offset of the decoder-head gradient stage inside its tile
     static constexpr int LDS_FLOATS = ARENA + 5 * TILE + 4 * SMALL + 64;   // +64: slack for tile over-reads past the last row
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
-    static constexpr int NXU = cdiv(ST, 8);                         // prefetch registers: thread = (row, 1/8 of the columns)
+    static constexpr int NXD = cdiv(DD_, 8), NXM = cdiv(M_, 8);     // prefetch registers: thread = (row, every 8th column)
+    static constexpr int NXU = NXD + NXM;
     static_assert(ST <= 64 && H_ <= 62, "tile-pair plan covers at most 64 columns");
     static_assert(DD_ <= 15 && DL_ <= 15, "heads are one 16-wide tile");
     static_assert(STG_F2 + DD_ * KS_H <= TILE && SMALL + H_ * KS_F0 + 16 <= TILE, "stage aliasing plan");
@@ -136,6 +137,8 @@ __device__ __forceinline__ float lrelu(float p, float slope) { return fmaxf(p, p
 __device__ __forceinline__ float flog(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
 
 #define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
+// LDS offsets are far below 2^23: full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
 // Phase body in two halves executed in opposite order by the two waves of a SIMD (waves w and w+4 share one):
 // while waves 0-3 run the matrix half, waves 4-7 run the vector half (Adam, restores), then they swap, so the
@@ -226,18 +229,18 @@ __device__ __forceinline__ void mm_dgrad(const float* yrow, const float* wcol, i
     };
     {
         int n0, n1; rows(0, n0, n1);
-        a[0] = ld2(yrow + 2 * q); b0[0] = ld2(wcol + n0 * KS); b1[0] = ld2(wcol + n1 * KS);
+        a[0] = ld2(yrow + 2 * q); b0[0] = ld2(wcol + mul24(n0, KS)); b1[0] = ld2(wcol + mul24(n1, KS));
     }
 #pragma unroll
     for (int t = 0; t < G; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         if (t + 1 < G) {
             int n0, n1; rows(t + 1, n0, n1);
-            a[nxt] = ld2(yrow + 8 * (t + 1) + 2 * q); b0[nxt] = ld2(wcol + n0 * KS); b1[nxt] = ld2(wcol + n1 * KS);
+            a[nxt] = ld2(yrow + 8 * (t + 1) + 2 * q); b0[nxt] = ld2(wcol + mul24(n0, KS)); b1[nxt] = ld2(wcol + mul24(n1, KS));
         } else {
             int n = 8 * G + q;
             if (8 * G + 3 >= N) n = min(n, N - 1);
-            at = yrow[8 * G + q]; bt = ld2(wcol + n * KS);
+            at = yrow[8 * G + q]; bt = ld2(wcol + mul24(n, KS));
         }
         SCHED_FENCE();
         acc[0] = mfma4(a[cur].x, b0[cur].x, acc[0]);
@@ -322,12 +325,12 @@ __device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* 
     const float* wrow[NW][2];
 #pragma unroll
     for (int m = 0; m < NW; ++m) {
-        wrow[m][0] = W[m] + min(col0, C::H - 1) * KS;
-        wrow[m][1] = W[m] + min(col0 + 1, C::H - 1) * KS;
+        wrow[m][0] = W[m] + mul24(min(col0, C::H - 1), KS);
+        wrow[m][1] = W[m] + mul24(min(col0 + 1, C::H - 1), KS);
         keep[m][0] = ZERO4;
         keep[m][1] = ZERO4;
     }
-    mm_fwd<NW, KS>(X + (16 * rt + c) * sx, wrow, q, keep);
+    mm_fwd<NW, KS>(X + mul24(16 * rt + c, sx), wrow, q, keep);
     const bool in0 = col0 < C::H, in1 = col0 + 1 < C::H;
     const float f0 = col0 == C::H ? 1.f : 0.f, f1 = col0 + 1 == C::H ? 1.f : 0.f;
 #pragma unroll
@@ -338,7 +341,7 @@ __device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* 
             const float v1 = in1 ? lrelu(keep[m][1][r], slope) : f1;
             keep[m][0][r] = v0;
             keep[m][1][r] = v1;
-            if (col0 < C::ST) st2(out[m] + (16 * rt + 4 * q + r) * C::ST + col0, v0, v1);
+            if (col0 < C::ST) st2(out[m] + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
         }
 }
 
@@ -350,7 +353,7 @@ __device__ __forceinline__ void restore_tile(const f32x4 (&keep)[2], float* out,
     const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (col0 < C::ST) st2(out + (16 * rt + 4 * q + r) * C::ST + col0, keep[0][r], keep[1][r]);
+        if (col0 < C::ST) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, keep[0][r], keep[1][r]);
 }
 
 // Head forward (one 16-wide tile per 16 rows; 4 waves): out[b][n] = epi(sum_k X[b][k] W[n][k]), n < N.  EXP: exp().
@@ -358,10 +361,10 @@ template <class C, int N, bool EXP>
 __device__ __forceinline__ void fwd_head(const float* X, const float* W, float* out, int rt) {
     const int lane = opaque_lane();
     const int c = lane & 15, q = lane >> 4;
-    const f32x4 acc = mm_fwd1<C::KS_H>(X + (16 * rt + c) * C::ST, W + min(c, N - 1) * C::KS_H, q);
+    const f32x4 acc = mm_fwd1<C::KS_H>(X + mul24(16 * rt + c, C::ST), W + mul24(min(c, N - 1), C::KS_H), q);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (c < N) out[(16 * rt + 4 * q + r) * C::SS + c] = EXP ? expf(acc[r]) : acc[r];
+        if (c < N) out[mul24(16 * rt + 4 * q, C::SS) + r * C::SS + c] = EXP ? expf(acc[r]) : acc[r];
 }
 
 // Hidden-layer dgrad: out[b][k] = mask(h[b][k]) * sum_n dY[b][n] W[n][k] for k < KB, 0 beyond.
@@ -372,16 +375,16 @@ __device__ __forceinline__ void dgrad_hidden(const float* dY, int sy, const floa
     const int c = lane & 15, q = lane >> 4;
     const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
     f32x4 acc[2] = {ZERO4, ZERO4};
-    mm_dgrad<NS, N, KS>(dY + (16 * rt + c) * sy, W + min(col0, KS - 2), q, acc);
+    mm_dgrad<NS, N, KS>(dY + mul24(16 * rt + c, sy), W + min(col0, KS - 2), q, acc);
     const bool in0 = col0 < KB, in1 = col0 + 1 < KB;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = 16 * rt + 4 * q + r;
+        const int row = mul24(16 * rt + 4 * q, C::ST) + r * C::ST;      // row offset in floats
         if (col0 < C::ST) {
-            const f32x2 h = ld2(hm + row * C::ST + col0);
+            const f32x2 h = ld2(hm + row + col0);
             const float v0 = in0 ? acc[0][r] * (h.x > 0.f ? 1.f : slope) : 0.f;
             const float v1 = in1 ? acc[1][r] * (h.y > 0.f ? 1.f : slope) : 0.f;
-            st2(out + row * C::ST + col0, v0, v1);
+            st2(out + row + col0, v0, v1);
         }
     }
 }
@@ -395,13 +398,13 @@ __device__ __forceinline__ void dgrad_hidden_reg(const float* dY, int sy, const 
     const int c = lane & 15, q = lane >> 4;
     const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
     f32x4 acc[2] = {ZERO4, ZERO4};
-    mm_dgrad<NS, N, KS>(dY + (16 * rt + c) * sy, W + min(col0, KS - 2), q, acc);
+    mm_dgrad<NS, N, KS>(dY + mul24(16 * rt + c, sy), W + min(col0, KS - 2), q, acc);
     const bool in0 = col0 < KB, in1 = col0 + 1 < KB;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float v0 = in0 ? acc[0][r] * (keep[0][r] > 0.f ? 1.f : slope) : 0.f;
         const float v1 = in1 ? acc[1][r] * (keep[1][r] > 0.f ? 1.f : slope) : 0.f;
-        if (col0 < C::ST) st2(out + (16 * rt + 4 * q + r) * C::ST + col0, v0, v1);
+        if (col0 < C::ST) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
     }
 }
 
@@ -546,21 +549,37 @@ __device__ __forceinline__ void philox_normal4(unsigned long long seed, unsigned
     out[0] = r0 * c0f; out[1] = r0 * s0; out[2] = r1 * c1f; out[3] = r1 * s1;
 }
 
-// Next batch [x | u] into registers: thread = (row b = tid >> 3, column slice tid & 7), element j of the slice is
-// tile column (tid & 7) * NXU + j.  Branch-free: columns outside x / u read a dummy address and get their
-// constant (1 in the bias column, 0 elsewhere).
+// Next batch [x | u] into registers: thread = (row b = tid >> 3, column phase p = tid & 7); it fetches x[row][p + 8j]
+// and u[row][p + 8j].  Every load instruction reads one array and is unconditional (out-of-range columns are
+// clamped to a valid element and simply not stored), so nothing here branches and no load waits on another.
 template <class C>
 __device__ __forceinline__ void load_xu(float (&xu)[C::NXU], int row, const float* xd, const float* ud) {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
-    const int k0 = (t & 7) * C::NXU;
+    const int ph = t & 7;
+    const float* xr = xd + (size_t)row * C::DD;
 #pragma unroll
-    for (int j = 0; j < C::NXU; ++j) {
-        const int k = k0 + j;
-        const bool is_x = k < C::DD, is_u = C::HAS_U && k >= C::UOFF && k < C::KIN;
-        const float* p = is_x ? xd + (size_t)row * C::DD + k : (is_u ? ud + (size_t)row * C::M + (k - C::UOFF) : xd);
-        const float val = *p;
-        xu[j] = (is_x || is_u) ? val : (k == C::KIN ? 1.f : 0.f);
+    for (int j = 0; j < C::NXD; ++j) xu[j] = xr[min(ph + 8 * j, C::DD - 1)];
+    if constexpr (C::HAS_U) {
+        const float* ur = ud + (size_t)row * C::M;
+#pragma unroll
+        for (int j = 0; j < C::NXM; ++j) xu[C::NXD + j] = ur[min(ph + 8 * j, C::M - 1)];
+    }
+}
+
+// ... and from the registers into the resident [x | u | 1] tile (the constant-1 and zero columns are written once
+// at kernel start and never touched again).
+template <class C>
+__device__ __forceinline__ void store_xu(const float (&xu)[C::NXU], float* tile) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int ph = t & 7;
+    float* dst = tile + (t >> 3) * C::ST + ph;
+#pragma unroll
+    for (int j = 0; j < C::NXD; ++j) if (8 * j + 7 < C::DD || ph + 8 * j < C::DD) dst[8 * j] = xu[j];
+    if constexpr (C::HAS_U) {
+#pragma unroll
+        for (int j = 0; j < C::NXM; ++j) if (8 * j + 7 < C::M || ph + 8 * j < C::M) dst[C::UOFF + 8 * j] = xu[C::NXD + j];
     }
 }
 
@@ -616,6 +635,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     state_load<C, L_V0>(gP, gM, gV, arena, am, av);
     state_load<C, L_V1>(gP, gM, gV, arena, am, av);
     state_load<C, L_V2>(gP, gM, gV, arena, am, av);
+    if (tid < FT_B) T3[tid * ST + C::KIN] = 1.f;      // constant-1 (bias) column of the resident input tile
     __syncthreads();
 
 #if defined(FT_PRIO_X)
@@ -650,11 +670,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         }
         neg_step = A.neg_step[s];
         inv_bc2 = A.inv_bc2_sqrt[s];
-        {
-            float* dst = T3 + (tid >> 3) * ST + (tid & 7) * C::NXU;
-#pragma unroll
-            for (int j = 0; j < C::NXU; ++j) if ((tid & 7) * C::NXU + j < ST) dst[j] = xu[j];
-        }
+        store_xu<C>(xu, T3);
         if (A.eps) {
             for (int e = tid; e < FT_B * DL; e += FT_THREADS) {
                 const int b = e / DL, k = e - b * DL;
@@ -666,8 +682,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const int el = tid * 4 + i; sZ[(el / DL) * SS + el % DL] = nrm[i]; }
         }
-        int next_row = 0;
-        if (s + 1 < A.n_steps) next_row = idxp[(size_t)(s + 1) * FT_B + (tid >> 3)];
+        // row index of the next step's batch (the last step re-reads its own: unconditional, so that the wait-count
+        // pass never sees a load that is pending on one path only and answers with a vmcnt(0) mid-phase)
+        const int next_row = idxp[(size_t)min(s + 1, A.n_steps - 1) * FT_B + (tid >> 3)];
         lds_barrier(); STAMP(1);
 
         // ---- F1: h1g -> T0, h1v -> T1 (one pass over the shared input)
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         }
         lds_barrier(); STAMP(2);
         // ---- F2: h2g -> T2, h2v -> T4; next batch's rows start to arrive in registers
-        if (s + 1 < A.n_steps) load_xu<C>(xu, next_row, xd, ud);
+        load_xu<C>(xu, next_row, xd, ud);
         {
             const float* const Wg[1] = {arena + C::off_of(L_G1)};
             float* const og[1] = {T2};
