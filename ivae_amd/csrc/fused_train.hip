@@ -129,7 +129,12 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #endif
 }
 __device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
-__device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = (f32x2){a, b}; }
+__device__ __forceinline__ void st2(float* p, float a, float b) {
+#ifdef FT_ABL_NOSTORE         // timing experiment only: results computed, (almost) never stored
+    if (a != 1.2345e30f) return;
+#endif
+    *reinterpret_cast<f32x2*>(p) = (f32x2){a, b};
+}
 // leaky ReLU for 0 <= slope <= 1 (checked on the host before launch): max(p, slope * p)
 __device__ __forceinline__ float lrelu(float p, float slope) { return fmaxf(p, p * slope); }
 
@@ -163,30 +168,37 @@ __device__ __forceinline__ void stagger(int w, FM&& matrix_half, FV&& vector_hal
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // acc[w][j] += X[row][k] * W_w[n_j][k], k in [0, KS), KS = 8G + 4.  xrow = X + row*sx, wrow[w][j] = W_w + n_j*KS.
+// Operand reads run PF k-groups ahead of the MFMAs (a ring of PF+1 register sets): one group of 4 MFMAs lasts
+// 128 cycles when the wave has the matrix pipe to itself, less than an LDS round trip under load.
+#ifndef FT_PF
+#define FT_PF 2
+#endif
 template <int NW, int KS>
 __device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&wrow)[NW][2], int q, f32x4 (&acc)[NW][2]) {
-    constexpr int G = (KS - 4) / 8;
+    constexpr int G = (KS - 4) / 8, PF = FT_PF, R = PF + 1;
     static_assert(KS == 8 * G + 4 && G >= 1, "row strides are 4*odd, >= 12");
-    f32x2 a[2], b[2][NW][2];
+    f32x2 a[R], b[R][NW][2];
     float at = 0.f, bt[NW][2];
-    a[0] = ld2(xrow + 2 * q);
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { b[0][w][0] = ld2(wrow[w][0] + 2 * q); b[0][w][1] = ld2(wrow[w][1] + 2 * q); }
-#pragma unroll
-    for (int t = 0; t < G; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        if (t + 1 < G) {
-            a[nxt] = ld2(xrow + 8 * (t + 1) + 2 * q);
+    auto fetch = [&](int t) {
+        if (t < G) {
+            a[t % R] = ld2(xrow + 8 * t + 2 * q);
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
-                b[nxt][w][0] = ld2(wrow[w][0] + 8 * (t + 1) + 2 * q);
-                b[nxt][w][1] = ld2(wrow[w][1] + 8 * (t + 1) + 2 * q);
+                b[t % R][w][0] = ld2(wrow[w][0] + 8 * t + 2 * q);
+                b[t % R][w][1] = ld2(wrow[w][1] + 8 * t + 2 * q);
             }
-        } else {
+        } else if (t == G) {
             at = xrow[8 * G + q];
 #pragma unroll
             for (int w = 0; w < NW; ++w) { bt[w][0] = wrow[w][0][8 * G + q]; bt[w][1] = wrow[w][1][8 * G + q]; }
         }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) fetch(t);
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const int cur = t % R;
+        fetch(t + PF);
         SCHED_FENCE();
 #pragma unroll
         for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(a[cur].x, b[cur][w][0].x, acc[w][0]); acc[w][1] = mfma4(a[cur].x, b[cur][w][1].x, acc[w][1]); }
@@ -219,29 +231,30 @@ __device__ __forceinline__ f32x4 mm_fwd1(const float* xrow, const float* wrow, i
 // clamped to a real row.  yrow = dY + row*sy, wcol = W + col0.
 template <int NS, int N, int KS>
 __device__ __forceinline__ void mm_dgrad(const float* yrow, const float* wcol, int q, f32x4 (&acc)[2]) {
-    constexpr int G = (NS - 4) / 8;
+    constexpr int G = (NS - 4) / 8, PF = FT_PF, R = PF + 1;
     static_assert(NS == 8 * G + 4 && G >= 1, "contraction lengths are 4*odd, >= 12");
-    f32x2 a[2], b0[2], b1[2], bt = {0.f, 0.f};
+    f32x2 a[R], b0[R], b1[R], bt = {0.f, 0.f};
     float at = 0.f;
-    auto rows = [&](int t, int& n0, int& n1) {
-        n0 = 8 * t + 2 * q; n1 = n0 + 1;
-        if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
-    };
-    {
-        int n0, n1; rows(0, n0, n1);
-        a[0] = ld2(yrow + 2 * q); b0[0] = ld2(wcol + mul24(n0, KS)); b1[0] = ld2(wcol + mul24(n1, KS));
-    }
-#pragma unroll
-    for (int t = 0; t < G; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        if (t + 1 < G) {
-            int n0, n1; rows(t + 1, n0, n1);
-            a[nxt] = ld2(yrow + 8 * (t + 1) + 2 * q); b0[nxt] = ld2(wcol + mul24(n0, KS)); b1[nxt] = ld2(wcol + mul24(n1, KS));
-        } else {
+    auto fetch = [&](int t) {
+        if (t < G) {
+            int n0 = 8 * t + 2 * q, n1 = n0 + 1;
+            if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
+            a[t % R] = ld2(yrow + 8 * t + 2 * q);
+            b0[t % R] = ld2(wcol + mul24(n0, KS));
+            b1[t % R] = ld2(wcol + mul24(n1, KS));
+        } else if (t == G) {
             int n = 8 * G + q;
             if (8 * G + 3 >= N) n = min(n, N - 1);
-            at = yrow[8 * G + q]; bt = ld2(wcol + mul24(n, KS));
+            at = yrow[8 * G + q];
+            bt = ld2(wcol + mul24(n, KS));
         }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) fetch(t);
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const int cur = t % R;
+        fetch(t + PF);
         SCHED_FENCE();
         acc[0] = mfma4(a[cur].x, b0[cur].x, acc[0]);
         acc[1] = mfma4(a[cur].x, b0[cur].y, acc[1]);
@@ -276,26 +289,49 @@ __device__ __forceinline__ f32x4 mm_dgrad1(const float* yrow, const float* wcol,
     return e + o;
 }
 
-// acc[j] += dY[b][n] * X[b][col0 + j], b in [0, 64).  ycol = dY + n, xcol = X + col0.  Groups of 4 batch k-steps.
-__device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float* xcol, int sx, int q, f32x4 (&acc)[2]) {
-    constexpr int G = FT_B / 16;
-    float a[2][4];
-    f32x2 b[2][4];
+// Interleave request for the scheduler inside one fenced region: `n` times {1 MFMA, then up to `valu` VALU and `ds`
+// LDS instructions}.  Independent vector work placed in the same region as a run of MFMAs is thereby issued in the
+// shadow of the matrix instructions (an MFMA holds the SIMD's issue port for 8 of its 32 cycles).
+template <int N, int VALU, int DS>
+__device__ __forceinline__ void interleave_mfma() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { a[0][i] = ycol[(4 * i + q) * sy]; b[0][i] = ld2(xcol + (4 * i + q) * sx); }
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (VALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+        if (DS > 0) __builtin_amdgcn_sched_group_barrier(0x080, DS, 0);
+    }
+}
+
+struct NoFill { __device__ __forceinline__ void operator()(int) const {} };
+
+// acc[j] += dY[b][n] * X[b][col0 + j], b in [0, 64).  ycol = dY + n, xcol = X + col0.  WG_G groups of 2 batch
+// k-steps (4 MFMAs each); fill(t) is independent vector work issued between the MFMAs of group t.
+#define WG_G (FT_B / 8)
+template <class F>
+__device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float* xcol, int sx, int q, f32x4 (&acc)[2], F&& fill) {
+    constexpr int PF = 2, R = PF + 1;
+    float a[R][2];
+    f32x2 b[R][2];
+    auto fetch = [&](int t) {
+        if (t < WG_G) {
 #pragma unroll
-    for (int t = 0; t < G; ++t) {
-        const int cur = t & 1, nxt = cur ^ 1;
-        if (t + 1 < G) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[nxt][i] = ycol[(16 * (t + 1) + 4 * i + q) * sy];
-                b[nxt][i] = ld2(xcol + (16 * (t + 1) + 4 * i + q) * sx);
+            for (int i = 0; i < 2; ++i) {
+                a[t % R][i] = ycol[(8 * t + 4 * i + q) * sy];
+                b[t % R][i] = ld2(xcol + (8 * t + 4 * i + q) * sx);
             }
         }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) fetch(t);
+#pragma unroll
+    for (int t = 0; t < WG_G; ++t) {
+        const int cur = t % R;
+        fetch(t + PF);
         SCHED_FENCE();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[0] = mfma4(a[cur][i], b[cur][i].x, acc[0]); acc[1] = mfma4(a[cur][i], b[cur][i].y, acc[1]); }
+        for (int i = 0; i < 2; ++i) { acc[0] = mfma4(a[cur][i], b[cur][i].x, acc[0]); acc[1] = mfma4(a[cur][i], b[cur][i].y, acc[1]); }
+        fill(t);
+        interleave_mfma<4, 5, 1>();
         SCHED_FENCE();
     }
 }
@@ -410,13 +446,13 @@ __device__ __forceinline__ void dgrad_hidden_reg(const float* dY, int sy, const 
 
 // Weight gradient of a layer with > 16 input columns: stage[n][k] = sum_b dY[b][n] X[b][k] for k <= KB (k == KB
 // is the bias gradient: X carries a constant-1 column there), 0 beyond.  Wave w: rows 16*(w&3).., column half w>>2.
-template <class C, int N, int KS, int KB, bool ROWGUARD = false>
-__device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float* X, int sx, float* stage, int w) {
+template <class C, int N, int KS, int KB, bool ROWGUARD = false, class F = NoFill>
+__device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float* X, int sx, float* stage, int w, F&& fill = F()) {
     const int lane = opaque_lane();
     const int c = lane & 15, q = lane >> 4;
     const int nt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
     f32x4 acc[2] = {ZERO4, ZERO4};
-    mm_wgrad(dY + min(16 * nt + c, sy - 1), sy, X + min(col0, KS - 2), sx, q, acc);
+    mm_wgrad(dY + min(16 * nt + c, sy - 1), sy, X + min(col0, KS - 2), sx, q, acc, fill);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = 16 * nt + 4 * q + r;       // rows >= N land in the tail of the (64-row) stage tile unless guarded
@@ -441,38 +477,60 @@ __device__ __forceinline__ void wgrad_tile(const float* dY, int sy, const float*
 // Adam for layer L: gradient from `stage` (same (N, KS) layout as the layer in the arena).
 // Same update as k_adam (adam.hip) / torch.optim.Adam; sqrt and the final divide use the hardware
 // v_sqrt_f32 / v_rcp_f32 (1 ulp) -- a <=2e-7 relative change of a step of size ~lr.
+template <class C, int L>
+struct AdamOp {
+    static constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L), CNT = C::cnt_of(L);
+    static constexpr int NS = CNT > 0 ? CNT : 1;
+    unsigned t;
+    float g[NS], p[NS];
+    float* base;
+
+    __device__ __forceinline__ unsigned offset(int j) const {
+        const unsigned idx = min(t + j * FT_THREADS, (unsigned)(P - 1));
+        const unsigned n = idx / (unsigned)KC;
+        return n * KS + (idx - n * KC);
+    }
+
+    // Branch-free: out-of-range slots work on a clamped (valid) element and only skip the store; their moment
+    // registers hold garbage that is never written back.  All LDS reads of the layer are issued here, before any math.
+    __device__ __forceinline__ void fetch(float* arena, const float* stage) {
+        base = arena + C::off_of(L);
+        t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+            const unsigned o = offset(j);
+            g[j] = stage[o];
+            p[j] = base[o];
+        }
+    }
+
+    // Same update as k_adam (adam.hip) / torch.optim.Adam; sqrt and the final divide use the hardware
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp) -- a <=2e-7 relative change of a step of size ~lr.
+    template <int NA>
+    __device__ __forceinline__ void slot(int j, float (&am)[NA], float (&av)[NA], float w1, float b2, float w2,
+                                         float neg_step, float inv_bc2, float eps) {
+        const float m0 = am[R0 + j], v0 = av[R0 + j];
+        const float mi = m0 + w1 * (g[j] - m0);
+        const float vi = v0 * b2 + (w2 * g[j]) * g[j];
+        const float denom = __builtin_amdgcn_sqrtf(vi) * inv_bc2 + eps;
+        const float pn = p[j] + (neg_step * mi) * __builtin_amdgcn_rcpf(denom);
+        am[R0 + j] = mi;
+        av[R0 + j] = vi;
+        if ((j + 1) * FT_THREADS <= P || t + j * FT_THREADS < (unsigned)P) base[offset(j)] = pn;
+    }
+};
+
+// Adam for layer L: gradient from `stage` (same (N, KS) layout as the layer in the arena).
 template <class C, int L, int NA>
 __device__ __forceinline__ void adam_layer(float* arena, const float* stage, float (&am)[NA], float (&av)[NA], float w1,
                                            float b2, float w2, float neg_step, float inv_bc2, float eps) {
-    constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L), CNT = C::cnt_of(L);
-    if constexpr (CNT > 0) {
-        float* base = arena + C::off_of(L);
-        unsigned t = threadIdx.x;
-        asm volatile("" : "+v"(t));
-        // Branch-free: out-of-range slots work on a clamped (valid) element and only skip the store; their moment
-        // registers hold garbage that is never written back.  All LDS reads of the layer are issued before any math.
-        unsigned off[CNT];
-        float g[CNT], p[CNT];
-#pragma unroll
-        for (int j = 0; j < CNT; ++j) {
-            const unsigned idx = min(t + j * FT_THREADS, (unsigned)(P - 1));
-            const unsigned n = idx / (unsigned)KC;
-            off[j] = n * KS + (idx - n * KC);
-            g[j] = stage[off[j]];
-            p[j] = base[off[j]];
-        }
+    if constexpr (C::cnt_of(L) > 0) {
+        AdamOp<C, L> op;
+        op.fetch(arena, stage);
         SCHED_FENCE();
 #pragma unroll
-        for (int j = 0; j < CNT; ++j) {
-            const float m0 = am[R0 + j], v0 = av[R0 + j];
-            const float mi = m0 + w1 * (g[j] - m0);
-            const float vi = v0 * b2 + (w2 * g[j]) * g[j];
-            const float denom = __builtin_amdgcn_sqrtf(vi) * inv_bc2 + eps;
-            const float pn = p[j] + (neg_step * mi) * __builtin_amdgcn_rcpf(denom);
-            am[R0 + j] = mi;
-            av[R0 + j] = vi;
-            if ((j + 1) * FT_THREADS <= P || t + j * FT_THREADS < (unsigned)P) base[off[j]] = pn;
-        }
+        for (int j = 0; j < C::cnt_of(L); ++j) op.slot(j, am, av, w1, b2, w2, neg_step, inv_bc2, eps);
     }
 }
 
@@ -511,9 +569,11 @@ template <class C, int L, int NA>
 __device__ __forceinline__ void state_store(float* gP, float* gM, float* gV, const float* arena, const float (&am)[NA],
                                             const float (&av)[NA]) {
     constexpr int P = C::p_of(L), KC = C::kb_of(L) + 1, KS = C::ks_of(L), R0 = C::reg_of(L);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));        // re-derive the indices here: values shared with state_load would live (spilled) across the step loop
 #pragma unroll
     for (int j = 0; j < C::cnt_of(L); ++j) {
-        const int idx = threadIdx.x + j * FT_THREADS;
+        const int idx = tid + j * FT_THREADS;
         if (idx < P) {
             const int n = idx / KC, k = idx - n * KC;
             const int gi = torch_index<C, L>(n, k);
@@ -647,6 +707,18 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     float xu[C::NXU];
     load_xu<C>(xu, idxp[tid >> 3], xd, ud);
     float neg_step = 0.f, inv_bc2 = 1.f;       // of the previous step (its last layer's Adam runs in P0)
+
+// Weight-gradient product of one layer with Adam of another layer (LA, gradient in stage_a) issued between its MFMAs.
+#define WGRAD_ADAM(N_, KS_, KB_, DY_, SY_, X_, SX_, STAGE_, LA_, STAGE_A_)                                              \
+    do {                                                                                                               \
+        AdamOp<C, LA_> op_;                                                                                            \
+        op_.fetch(arena, STAGE_A_);                                                                                    \
+        wgrad_pair<C, N_, KS_, KB_>(DY_, SY_, X_, SX_, STAGE_, w, [&](int t_) __attribute__((always_inline)) {           \
+            constexpr int CNT_ = AdamOp<C, LA_>::CNT;                                                                  \
+            _Pragma("unroll") for (int j_ = 0; j_ < CNT_; ++j_)                                                        \
+                if (j_ * WG_G / (CNT_ > 0 ? CNT_ : 1) == t_) op_.slot(j_, am, av, w1, b2, w2, neg_step, inv_bc2, aeps);   \
+        });                                                                                                            \
+    } while (0)
 
 #ifdef FT_ABL_NOADAM           // timing experiment only
 #define ADAM(L_, STAGE_) ((void)0)
@@ -850,8 +922,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_G2, sZ); });
         lds_barrier(); STAMP(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
-        stagger(w, LAMBDA { wgrad_pair<C, H, KS_E0, C::KIN>(T2, ST, T3, ST, T0, w); },
-                LAMBDA { ADAM(L_G1, T1); restore_tile<C>(k2v, T4, w); });
+        WGRAD_ADAM(H, KS_E0, C::KIN, T2, ST, T3, ST, T0, L_G1, T1);
+        restore_tile<C>(k2v, T4, w);
         lds_barrier(); STAMP(15);
 
         // ---- V3: d2v -> T1; head gradient -> sZ; Adam(G0); h1v -> T2
@@ -865,8 +937,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 LAMBDA { wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w); ADAM(L_V2, sZ); });
         lds_barrier(); STAMP(17);
         // ---- V1: layer-1 gradient -> T1; Adam(V1); h2l -> T2
-        stagger(w, LAMBDA { wgrad_pair<C, H, KS_E0, C::KIN>(T4, ST, T3, ST, T1, w); },
-                LAMBDA { ADAM(L_V1, T0); if constexpr (C::HAS_U) restore_tile<C>(k2l, T2, w); });
+        WGRAD_ADAM(H, KS_E0, C::KIN, T4, ST, T3, ST, T1, L_V1, T0);
+        if constexpr (C::HAS_U) restore_tile<C>(k2l, T2, w);
         lds_barrier(); STAMP(18);
 
         if constexpr (C::HAS_U) {
@@ -881,7 +953,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                     LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_L2, sZ); });
             lds_barrier(); STAMP(20);
             // ---- L1: layer-1 gradient -> T0; Adam(L1)
-            stagger(w, LAMBDA { wgrad_pair<C, H, KS_L0, M>(T2, ST, T3 + C::UOFF, ST, T0, w); }, LAMBDA { ADAM(L_L1, T1); });
+            WGRAD_ADAM(H, KS_L0, M, T2, ST, T3 + C::UOFF, ST, T0, L_L1, T1);
             lds_barrier(); STAMP(21);
         }
     }
