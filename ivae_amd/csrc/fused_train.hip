@@ -45,8 +45,18 @@ __device__ unsigned long long* g_ft_prof = nullptr;
             g_ft_prof[(size_t)s * FT_NSTAMP + (i)] = t_;                                           \
         }                                                                                          \
     } while (0)
+// sub-phase stamps of wave 0 (slots 32+i) and wave 4 (slots 48+i), i < 16
+#define STAMPW(i)                                                                                  \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256) && g_ft_prof) {            \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            g_ft_prof[(size_t)s * FT_NSTAMP + 32 + (threadIdx.x >> 4) + (i)] = t_;                 \
+        }                                                                                          \
+    } while (0)
 #else
 #define STAMP(i)
+#define STAMPW(i)
 #endif
 
 #define FT_THREADS 512
@@ -105,7 +115,9 @@ struct FCfg {
 // addresses out of the step loop (dozens of phases x several VGPRs each -> spills).
 __device__ __forceinline__ int opaque_lane() {
     int l = threadIdx.x & 63;
+#ifndef FT_TRANSPARENT_LANE
     asm volatile("" : "+v"(l));
+#endif
     return l;
 }
 
@@ -167,14 +179,29 @@ __device__ __forceinline__ void stagger(int w, FM&& matrix_half, FV&& vector_hal
 // of group t and pins that order with scheduling barriers; the wait-count pass then emits counted lgkmcnt waits.
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Interleave request for the scheduler inside one fenced region: `n` times {1 MFMA, then up to `valu` VALU and `ds`
+// LDS instructions}.  Independent vector work placed in the same region as a run of MFMAs is thereby issued in the
+// shadow of the matrix instructions (an MFMA holds the SIMD's issue port for 8 of its 32 cycles).
+template <int N, int VALU, int DS>
+__device__ __forceinline__ void interleave_mfma() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (VALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
+        if (DS > 0) __builtin_amdgcn_sched_group_barrier(0x080, DS, 0);
+    }
+}
+
+struct NoFill { __device__ __forceinline__ void operator()(int) const {} };
+
 // acc[w][j] += X[row][k] * W_w[n_j][k], k in [0, KS), KS = 8G + 4.  xrow = X + row*sx, wrow[w][j] = W_w + n_j*KS.
 // Operand reads run PF k-groups ahead of the MFMAs (a ring of PF+1 register sets): one group of 4 MFMAs lasts
 // 128 cycles when the wave has the matrix pipe to itself, less than an LDS round trip under load.
 #ifndef FT_PF
 #define FT_PF 2
 #endif
-template <int NW, int KS>
-__device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&wrow)[NW][2], int q, f32x4 (&acc)[NW][2]) {
+template <int NW, int KS, class F>
+__device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&wrow)[NW][2], int q, f32x4 (&acc)[NW][2], F&& fill) {
     constexpr int G = (KS - 4) / 8, PF = FT_PF, R = PF + 1;
     static_assert(KS == 8 * G + 4 && G >= 1, "row strides are 4*odd, >= 12");
     f32x2 a[R], b[R][NW][2];
@@ -204,6 +231,8 @@ __device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&w
         for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(a[cur].x, b[cur][w][0].x, acc[w][0]); acc[w][1] = mfma4(a[cur].x, b[cur][w][1].x, acc[w][1]); }
 #pragma unroll
         for (int w = 0; w < NW; ++w) { acc[w][0] = mfma4(a[cur].y, b[cur][w][0].y, acc[w][0]); acc[w][1] = mfma4(a[cur].y, b[cur][w][1].y, acc[w][1]); }
+        fill(t);                                 // independent vector work, issued between this group's MFMAs
+        interleave_mfma<4 * NW, 4, 1>();
         SCHED_FENCE();
     }
 #pragma unroll
@@ -289,21 +318,6 @@ __device__ __forceinline__ f32x4 mm_dgrad1(const float* yrow, const float* wcol,
     return e + o;
 }
 
-// Interleave request for the scheduler inside one fenced region: `n` times {1 MFMA, then up to `valu` VALU and `ds`
-// LDS instructions}.  Independent vector work placed in the same region as a run of MFMAs is thereby issued in the
-// shadow of the matrix instructions (an MFMA holds the SIMD's issue port for 8 of its 32 cycles).
-template <int N, int VALU, int DS>
-__device__ __forceinline__ void interleave_mfma() {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (VALU > 0) __builtin_amdgcn_sched_group_barrier(0x002, VALU, 0);
-        if (DS > 0) __builtin_amdgcn_sched_group_barrier(0x080, DS, 0);
-    }
-}
-
-struct NoFill { __device__ __forceinline__ void operator()(int) const {} };
-
 // acc[j] += dY[b][n] * X[b][col0 + j], b in [0, 64).  ycol = dY + n, xcol = X + col0.  WG_G groups of 2 batch
 // k-steps (4 MFMAs each); fill(t) is independent vector work issued between the MFMAs of group t.
 #define WG_G (FT_B / 8)
@@ -352,10 +366,25 @@ __device__ __forceinline__ f32x4 mm_wgrad1(const float* ycol, int sy, const floa
 
 // Hidden layer(s) forward for NW weight matrices that share the input tile:
 // out_w[b][n] = lrelu(sum_k X[b][k] W_w[n][k]) for n < H, 1 at n == H (bias column of the next layer), 0 beyond.
-template <class C, int NW, int KS>
-__device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* const (&W)[NW], float* const (&out)[NW],
-                                           float slope, int w, f32x4 (&keep)[NW][2]) {
-    const int lane = opaque_lane();
+// Epilogue of one accumulator row r of a hidden-layer tile pair: activation, constant-1 / zero columns, store,
+// and the value kept for the stash.
+template <class C>
+__device__ __forceinline__ void fwd_epilogue_row(f32x4 (&keep)[2], int r, float* out, float slope, int w, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    const bool in0 = col0 < C::H, in1 = col0 + 1 < C::H;
+    const float f0 = col0 == C::H ? 1.f : 0.f, f1 = col0 + 1 == C::H ? 1.f : 0.f;
+    const float v0 = in0 ? lrelu(keep[0][r], slope) : f0;
+    const float v1 = in1 ? lrelu(keep[1][r], slope) : f1;
+    keep[0][r] = v0;
+    keep[1][r] = v1;
+    if (col0 < C::ST) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
+}
+
+// Product of hidden layer(s) for NW weight matrices that share the input tile: acc_w = X W_w^T (no epilogue).
+template <class C, int NW, int KS, class F>
+__device__ __forceinline__ void fwd_product(const float* X, int sx, const float* const (&W)[NW], int w, int lane,
+                                            f32x4 (&keep)[NW][2], F&& fill) {
     const int c = lane & 15, q = lane >> 4;
     const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
     const float* wrow[NW][2];
@@ -366,19 +395,20 @@ __device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* 
         keep[m][0] = ZERO4;
         keep[m][1] = ZERO4;
     }
-    mm_fwd<NW, KS>(X + mul24(16 * rt + c, sx), wrow, q, keep);
-    const bool in0 = col0 < C::H, in1 = col0 + 1 < C::H;
-    const float f0 = col0 == C::H ? 1.f : 0.f, f1 = col0 + 1 == C::H ? 1.f : 0.f;
+    mm_fwd<NW, KS>(X + mul24(16 * rt + c, sx), wrow, q, keep, fill);
+}
+
+// Hidden layer(s) forward for NW weight matrices that share the input tile:
+// out_w[b][n] = lrelu(sum_k X[b][k] W_w[n][k]) for n < H, 1 at n == H (bias column of the next layer), 0 beyond.
+template <class C, int NW, int KS>
+__device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* const (&W)[NW], float* const (&out)[NW],
+                                           float slope, int w, f32x4 (&keep)[NW][2]) {
+    const int lane = opaque_lane();
+    fwd_product<C, NW, KS>(X, sx, W, w, lane, keep, NoFill());
 #pragma unroll
     for (int m = 0; m < NW; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v0 = in0 ? lrelu(keep[m][0][r], slope) : f0;
-            const float v1 = in1 ? lrelu(keep[m][1][r], slope) : f1;
-            keep[m][0][r] = v0;
-            keep[m][1][r] = v1;
-            if (col0 < C::ST) st2(out[m] + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
-        }
+        for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(keep[m], r, out[m], slope, w, lane);
 }
 
 // Write a stashed hidden activation (post-epilogue values kept in registers) back to an LDS tile.
@@ -772,17 +802,25 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         // ---- F2: h2g -> T2, h2v -> T4; next batch's rows start to arrive in registers
         load_xu<C>(xu, next_row, xd, ud);
         {
+            const int ln = opaque_lane();
             const float* const Wg[1] = {arena + C::off_of(L_G1)};
-            float* const og[1] = {T2};
-            f32x4 keep[1][2];
-            fwd_hidden<C, 1, KS_H>(T0, ST, Wg, og, slope, w, keep);
-            k2g[0] = keep[0][0]; k2g[1] = keep[0][1];
             const float* const Wv[1] = {arena + C::off_of(L_V1)};
-            float* const ov[1] = {T4};
-            fwd_hidden<C, 1, KS_H>(T1, ST, Wv, ov, slope, w, keep);
-            k2v[0] = keep[0][0]; k2v[1] = keep[0][1];
+            f32x4 kg[1][2], kv[1][2];
+            STAMPW(0);
+            fwd_product<C, 1, KS_H>(T0, ST, Wg, w, ln, kg, NoFill());
+            STAMPW(1);
+            // epilogue of the g tile pair row by row between the MFMAs of the v product
+            fwd_product<C, 1, KS_H>(T1, ST, Wv, w, ln, kv, [&](int t) __attribute__((always_inline)) {
+                if (t < 4) fwd_epilogue_row<C>(kg[0], t, T2, slope, w, ln);
+            });
+            STAMPW(2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(kv[0], r, T4, slope, w, ln);
+            STAMPW(3);
+            k2g[0] = kg[0][0]; k2g[1] = kg[0][1];
+            k2v[0] = kv[0][0]; k2v[1] = kv[0][1];
         }
-        lds_barrier(); STAMP(3);
+        lds_barrier(); STAMP(3); STAMPW(4);
         // ---- F3: heads g -> sG (waves 0-3), v = exp(logv) -> sV (waves 4-7); prior layer 1: h1l -> T0
         if (w < 4) fwd_head<C, DL, false>(T2, arena + C::off_of(L_G2), sG, rt);
         else fwd_head<C, DL, true>(T4, arena + C::off_of(L_V2), sV, rt);

@@ -1,3 +1,5 @@
+"""Per-tensor error report of ivae_train_steps against the CPU oracle (debug aid for kernel work).
+usage: dbg_fused.py [fixture | shape:dd,dl,M] [n_steps] [tensor-name for a 16x16 tile error map]"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from ivae_amd import ops
@@ -30,41 +32,15 @@ for n in names:
     print(f"{n:18s} perr max {e.max():.2e} mean {e.mean():.2e}  m relerr {em:.2e}  argmax {e.argmax()} shape {P[n].shape}")
     off += k
 off = 0
-for n in names:
-    k = P[n].size
-    if n == (sys.argv[3] if len(sys.argv) > 3 else "f.fc.1.weight"):
-        G = gm[off:off+k].reshape(P[n].shape); R = M[n]
-        E = np.abs(G - R) / np.abs(R).max()
-        print("tile error map (rows n/16, cols k/16):")
-        for i in range(0, E.shape[0], 16):
-            print(["%.1e" % E[i:i+16, j:j+16].max() for j in range(0, E.shape[1], 16)])
-        bad = np.argwhere(E > 1e-3)
-        print("bad count", len(bad), "rows", sorted(set(bad[:,0]))[:70], "cols", sorted(set(bad[:,1]))[:70])
-    off += k
-gv = v1[0].cpu().numpy(); P0f = flat(c.params, names); off = 0
-for n in names:
-    k = P[n].size
-    if n == (sys.argv[3] if len(sys.argv) > 3 else "f.fc.1.weight"):
-        a, b = 1495, 1506
-        print("m got", gm[off+a:off+b]); print("m ref", M[n].reshape(-1)[a:b])
-        print("v got", gv[off+a:off+b]); print("dp got", (got - P0f)[off+a:off+b]); 
-        a, b = 2045, 2056
-        print("m got", gm[off+a:off+b]); print("m ref", M[n].reshape(-1)[a:b]); print("dp got", (got - P0f)[off+a:off+b])
-    off += k
-off = 0
-for n in names:
-    k = P[n].size
-    if n == (sys.argv[3] if len(sys.argv) > 3 else "f.fc.1.weight"):
-        e = np.abs(gm[off:off+k] - M[n].reshape(-1)) > 1e-3 * np.abs(M[n]).max()
-        idxs = np.nonzero(e)[0]
-        # contiguous ranges
-        rs = []; st = None
-        for i in idxs:
-            if st is None: st = pv = i
-            elif i != pv + 1: rs.append((st, pv)); st = i
-            pv = i
-        if st is not None: rs.append((st, pv))
-        print("bad ranges", rs[:40], "n", len(idxs))
-        ratio = gm[off:off+k][idxs] / M[n].reshape(-1)[idxs]
-        print("ratio stats", np.percentile(ratio, [0, 50, 100]))
-    off += k
+if len(sys.argv) > 3:
+    off = 0
+    for n in names:
+        k = P[n].size
+        if n == sys.argv[3]:
+            G = gm[off:off + k].reshape(P[n].shape)
+            E = np.abs(G - M[n]) / np.abs(M[n]).max()
+            print("exp_avg tile error map of", n, "(rows /16, cols /16):")
+            for i in range(0, E.shape[0], 16):
+                print(["%.1e" % E[i:i + 16, j:j + 16].max() for j in range(0, max(E.shape[1] if E.ndim > 1 else 1, 1), 16)]
+                      if E.ndim > 1 else "%.1e" % E[i:i + 16].max())
+        off += k

@@ -40,9 +40,10 @@ tot = mean.sum()
 print(f"models={M}  cycles/step (wave 0 of model 0): {tot:.0f}")
 for l, c in zip(LABELS, mean):
     print(f"  {l:28s} {c:9.0f}  {100*c/tot:5.1f}%")
-# sub-phase stamps of the G1 phase: wave 0 (slots 32..) and wave 4 (slots 48..); 0 = phase start, 1 = after the
-# matrix half, 2 = after Adam, 3 = after restore, 4 = both halves done
+# sub-phase stamps of the F2 phase: wave 0 (slots 32..) and wave 4 (slots 48..): 0 = before product g, 1 = after its
+# MFMAs, 2 = after product v (+ epilogue g in its shadow), 3 = after epilogue v, 4 = after the barrier
 raw = buf.cpu().numpy().reshape(steps, 64).astype(np.float64)[6:]
 for wv, base in (("wave0", 32), ("wave4", 48)):
     d = raw[:, base:base + 5] - raw[:, base:base + 1]
-    print(wv, "G1 sub-stamps (cycles from phase start):", np.round(d.mean(0)).astype(int).tolist())
+    print(wv, "F2 sub-stamps (cycles from the first):", np.round(d.mean(0)).astype(int).tolist())
+print("F2 phase start (STAMP 2) -> first sub-stamp, wave0:", int(np.round((raw[:, 32] - raw[:, 2]).mean())))
