@@ -1,0 +1,735 @@
+// Shape-generic ELBO forward / backward kernels on the fp32 matrix cores (any dims, activation, depth).
+//
+// One 256-thread workgroup (4 waves) owns a tile of TR = 16/32/64 batch rows of one model.  Every layer product
+// (forward, input gradient, weight gradient) is the same "row-row" contraction
+//
+//        out[i][j] = sum_k  A[i][k] * Bm[j][k]          (v_mfma_f32_16x16x4_f32, exact fp32 FMA chain)
+//
+// with A resident in LDS (activation / delta tiles, row stride 4*odd floats so that 128-bit operand reads spread
+// over the banks) and Bm streamed through LDS in 64 x 64 chunks:
+//   forward      A = layer input  [row][k]      Bm = W[n][k]  (+ bias as column K: inputs carry a constant-1 column)
+//   dgrad        A = delta        [row][n]      Bm = W^T[k][n]
+//   wgrad        A = delta^T      [n][row]      Bm = input^T[k][row]  (+ a row of ones: bias gradient)
+// A lane loads 4 consecutive k of its row as one ds_read_b128 and feeds them to 4 MFMAs; both operands use the same
+// k permutation, so sums are unchanged up to fp32 order.  The chunks are double-buffered in LDS and their global loads
+// are issued one chunk ahead into registers (also across layer boundaries), so the L2 latency of the weights hides
+// behind the previous chunk's MFMAs.  Hidden pre-activations go to the caller's workspace feature-major
+// ((H, Bp), Bp = batch rounded up to 64) so that the backward pass reads them as transposed operands directly.
+// Weight gradients are written as per-tile slabs and summed in a fixed order by k_reduce: results are bitwise
+// reproducible run to run (no float atomics).
+//
+// Reference arithmetic restated here: models/nets.py:114-121 (MLP.forward), 301-314 (Normal.sample / log_pdf),
+// 45-52 (log_normal), 450-475, 587-599, 165-185, 224-243 (forward / elbo of the four model classes); backward =
+// what autograd derives from those (SURVEY.md §8 a-bwd).
+#include <hip/hip_runtime.h>
+#include "layout.h"
+#include "kernels.h"
+
+#define NT 256
+#define KCH 64            // contraction extent of a staged chunk
+#define NCH 64            // rows (output columns) of a staged chunk
+#define LDC 68            // chunk row stride (4 * odd)
+#define CHUNK (NCH * LDC)
+#define LOG2PI 1.8378770664093453f
+
+// Diagnostic build only (-DMF_PROF): s_memtime stamps of workgroup 0 / thread 0 go to a buffer of their own; no
+// output depends on them and the shipped library contains none.
+#ifdef MF_PROF
+__device__ unsigned long long* g_mf_prof = nullptr;
+#define MSTAMP(id)                                                                                  \
+    do {                                                                                            \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_mf_prof && St.n < 2000) {    \
+            unsigned long long t_;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            g_mf_prof[2 * St.n] = (id);                                                             \
+            g_mf_prof[2 * St.n + 1] = t_;                                                           \
+            ++St.n;                                                                                 \
+        }                                                                                           \
+    } while (0)
+extern "C" int ivae_debug_set_prof_mf(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mf_prof), &buf, sizeof(buf));
+}
+#else
+#define MSTAMP(id)
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
+
+__device__ __forceinline__ int up16(int x) { return (x + 15) & ~15; }
+
+__device__ __forceinline__ float act_fwd(float p, int act, float slope) {
+    switch (act) {
+        case IVAE_ACT_LRELU: return p > 0.f ? p : p * slope;
+        case IVAE_ACT_XTANH: return tanhf(p) + slope * p;
+        case IVAE_ACT_SIGMOID: return 1.f / (1.f + expf(-p));
+        default: return p;
+    }
+}
+
+__device__ __forceinline__ float act_bwd(float p, int act, float slope) {
+    switch (act) {
+        case IVAE_ACT_LRELU: return p > 0.f ? 1.f : slope;
+        case IVAE_ACT_XTANH: { float t = tanhf(p); return 1.f - t * t + slope; }
+        case IVAE_ACT_SIGMOID: { float s = 1.f / (1.f + expf(-p)); return s * (1.f - s); }
+        default: return 1.f;
+    }
+}
+
+// ------------------------------------------------------------------------------ streamed operand
+// Source of the streamed operand Bm[j][k] (j: output column, k: contraction index) of one product.
+//   SRC_W    forward:  Bm[j][k] = W[j][k] (W is (J, K) row-major at p), Bm[j][K] = bias[j] (at p + d2): the A tiles
+//            carry a constant-1 column at k = K.  k in [hole0, hole0 + hole) is padding (zero) and later k shift
+//            down by `hole` ([x | pad | u | 1] input tiles).
+//   SRC_WT   dgrad:    Bm[j][k] = W[k][j]   (W is (K, J) row-major at p, row stride ld)
+//   SRC_PRE  wgrad of a hidden layer:  Bm[j][k] = act(preT[j][k]) (pre-activations feature-major at p, row stride ld,
+//            k = batch row < K), Bm[J][k] = 1 (its result row is the bias gradient)
+//   SRC_ROWS wgrad of a first layer:   Bm[j][k] = in[k][j], in = [a | b] row-major blocks (a: J1 columns at p, row
+//            stride ld; b: J - J1 columns at p + d2, row stride ld2), Bm[J][k] = 1
+// Everything outside the stated extents is zero.
+enum { SRC_NONE = 0, SRC_W, SRC_WT, SRC_PRE, SRC_ROWS };
+struct BSrc {
+    const float* p;
+    long d2;
+    int kind;
+    int J1, J, K;
+    int ld, ld2;
+    int hole0, hole;
+    int act; float slope;
+};
+
+// One 64 x 64 chunk (j0.., k0..) moves through 16 registers per thread.  LOAD: issue the global loads (unconditional,
+// from always-valid addresses: nothing here waits for memory).  !LOAD: registers -> LDS chunk buffer wb, applying the
+// zero / one fill and the activation.  Element e of thread (w = wave, l = lane):
+//   direct kinds (W, PRE: global memory contiguous along k):  j = w + 4e, k = l
+//   transposing kinds (WT, ROWS: contiguous along j):         j = (l & 7) + 8w + 32(e & 1), k = (l >> 3) + 8(e >> 1)
+//   (8 consecutive j x 8 k per wave keep both the 32-B global segments and the LDS banks of the transposed store distinct)
+template <bool LOAD>
+__device__ __forceinline__ void chunk_io(float (&r)[16], const BSrc& S, int j0, int k0, float* wb) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));       // opaque: keeps the per-element addresses of every call site from being hoisted
+                                        // out of the layer loops (hundreds of live registers otherwise)
+    const int w = tid >> 6, l = tid & 63;
+    const float* __restrict__ p = S.p;
+    // every element is ONE load; out-of-range elements read a clamped (valid) address and are replaced when the
+    // chunk is stored: min/select only, no control flow; offsets advance by uniform strides from one per-thread base
+    if (S.kind == SRC_W) {
+        int k = k0 + l;
+        const bool in_hole = k >= S.hole0 && k < S.hole0 + S.hole;
+        if (k >= S.hole0 + S.hole) k -= S.hole;
+        const bool in_k = k < S.K && !in_hole, is_b = k == S.K && !in_hole;
+        const int kc = min(k, S.K - 1);
+        // row j = j0 + w + 4e: weight W[j][kc] or bias[j]; rows past the end clamp to the last one
+        const int step = is_b ? 4 : 4 * S.ld;
+        const int base = is_b ? (int)S.d2 + j0 + w : (j0 + w) * S.ld + kc;
+        const int last = is_b ? (int)S.d2 + S.J - 1 : (S.J - 1) * S.ld + kc;
+        const int jlim = S.J - j0 - w;                     // element e is a real row iff 4e < jlim
+        float* dst = wb + w * LDC + l;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (LOAD) r[e] = p[min(base + e * step, last)];
+            else dst[e * 4 * LDC] = ((in_k || is_b) && 4 * e < jlim) ? r[e] : 0.f;
+        }
+    } else if (S.kind == SRC_PRE) {
+        const int k = k0 + l;
+        const bool in_k = k < S.K;
+        const int base = (j0 + w) * S.ld + k, last = (S.J - 1) * S.ld + k;   // k < 64 <= Bp - row0: inside the padded row
+        const int jlim = S.J - j0 - w;
+        float* dst = wb + w * LDC + l;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (LOAD) r[e] = p[min(base + e * 4 * S.ld, last)];
+            else dst[e * 4 * LDC] = (in_k && 4 * e < jlim) ? act_fwd(r[e], S.act, S.slope) : (in_k && 4 * e == jlim) ? 1.f : 0.f;
+        }
+    } else if (S.kind == SRC_WT) {
+        const int jl = (l & 7) + 8 * w, kl = l >> 3;
+        const int ja = j0 + jl, jb = ja + 32;
+        const int oj[2] = {min(ja, S.J - 1), min(jb, S.J - 1)};
+        const bool vj[2] = {ja < S.J, jb < S.J};
+        float* dst = wb + jl * LDC + kl;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = k0 + kl + 8 * (e >> 1);
+            if (LOAD) r[e] = p[min(k, S.K - 1) * S.ld + oj[e & 1]];
+            else dst[32 * (e & 1) * LDC + 8 * (e >> 1)] = (vj[e & 1] && k < S.K) ? r[e] : 0.f;
+        }
+    } else if (S.kind == SRC_ROWS) {
+        const int jl = (l & 7) + 8 * w, kl = l >> 3;
+        const bool two = S.J > S.J1;
+        const int ja = j0 + jl, jb = ja + 32;
+        // column offset inside a row of block a (stride ld) or block b (stride ld2, at p + d2)
+        const bool inb[2] = {two && ja >= S.J1, two && jb >= S.J1};
+        const long cj[2] = {inb[0] ? S.d2 + (min(ja, S.J - 1) - S.J1) : (long)min(ja, S.J1 - 1),
+                            inb[1] ? S.d2 + (min(jb, S.J - 1) - S.J1) : (long)min(jb, S.J1 - 1)};
+        const int rs[2] = {inb[0] ? S.ld2 : S.ld, inb[1] ? S.ld2 : S.ld};
+        const int vj[2] = {ja < S.J ? 1 : ja == S.J ? 2 : 0, jb < S.J ? 1 : jb == S.J ? 2 : 0};
+        float* dst = wb + jl * LDC + kl;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = k0 + kl + 8 * (e >> 1);
+            if (LOAD) r[e] = p[cj[e & 1] + (long)(min(k, S.K - 1) * rs[e & 1])];
+            else dst[32 * (e & 1) * LDC + 8 * (e >> 1)] = k < S.K ? (vj[e & 1] == 1 ? r[e] : vj[e & 1] == 2 ? 1.f : 0.f) : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void chunk_load(float (&r)[16], const BSrc& S, int j0, int k0) {
+    chunk_io<true>(r, S, j0, k0, nullptr);
+}
+__device__ __forceinline__ void chunk_store(float (&r)[16], const BSrc& S, int j0, int k0, float* wb) {
+    chunk_io<false>(r, S, j0, k0, wb);
+}
+
+// ------------------------------------------------------------------------------ the contraction
+struct Stream {           // chunk pipeline state carried from one product to the next
+    float r[16];          // prefetched first chunk of the next product
+    float* wbuf;          // two chunk buffers
+    int par;              // which one the next chunk goes to
+    int n;                // diagnostic build: stamps written so far
+};
+
+// out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RT (RT <= RTE row tiles), j < Jn, k < Kc.
+// RTE (1, 2 or 4) fixes the wave -> tile map at compile time: wave w owns row tile w % RTE and the NTW = RTE column
+// tiles (w / RTE) + (4 / RTE) * t of every 64-column block, so the MFMA loop has no data-dependent control flow; tiles
+// and k-steps beyond the real extents multiply zero-filled chunk rows / columns (the epilogue drops them).
+// On entry St.r holds chunk (0, 0) of S; on exit it holds chunk (0, 0) of `next` (if any).
+// epi(rt, col0, acc): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3.
+template <int RTE, class EPI>
+__device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, int Jn, int Kc, const BSrc& next,
+                                          Stream& St, EPI&& epi) {
+    constexpr int WN = 4 / RTE, NTW = RTE;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int rt = wave % RTE, cg = wave / RTE;
+    const bool active = rt < RT;
+    const int K16 = up16(Kc);
+    for (int j0 = 0; j0 < Jn; j0 += NCH) {
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = ZERO4;
+        for (int k0 = 0; k0 < K16; k0 += KCH) {
+            const int nk = min(KCH, K16 - k0) >> 4;
+            float* wb = St.wbuf + St.par * CHUNK;
+            St.par ^= 1;
+            MSTAMP(1);
+            chunk_store(St.r, S, j0, k0, wb);
+            MSTAMP(2);
+            __syncthreads();
+            MSTAMP(3);
+            // prefetch: next k chunk, else next column block, else the following product's first chunk
+            if (k0 + KCH < K16) chunk_load(St.r, S, j0, k0 + KCH);
+            else if (j0 + NCH < Jn) chunk_load(St.r, S, j0 + NCH, 0);
+            else chunk_load(St.r, next, 0, 0);
+            MSTAMP(4);
+            if (active) {
+                const float* ap = A + (16 * rt + c) * lda + k0 + 4 * q;
+                const float* bp = wb + (16 * cg + c) * LDC + 4 * q;
+                // operands of k-step i+1 are read before the MFMAs of step i
+                f32x4 av = *reinterpret_cast<const f32x4*>(ap), bv[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp + t * WN * 16 * LDC);
+                for (int i = 0; i < nk; ++i) {
+                    const f32x4 a0 = av;
+                    f32x4 b0[NTW];
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) b0[t] = bv[t];
+                    const int in = min(i + 1, nk - 1) * 16;       // (the last step re-reads itself: branch-free)
+                    av = *reinterpret_cast<const f32x4*>(ap + in);
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp + t * WN * 16 * LDC + in);
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[x], b0[t][x], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        MSTAMP(5);
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) epi(rt, j0 + 16 * (cg + WN * t), acc[t]);
+        }
+        MSTAMP(6);
+    }
+}
+
+// ------------------------------------------------------------------------------ forward
+struct FwdCtx {
+    const float* P;        // this model's parameters
+    float* wsm;            // this model's workspace
+    int row0, nrows, RT;
+    float* h0;             // hidden tiles (TR, ldh), column H = 1
+    float* h1;
+};
+
+__device__ __forceinline__ BSrc src_none() {
+    BSrc S = {};
+    S.hole0 = 0x3fffffff;
+    return S;
+}
+// forward operand of layer li
+__device__ __forceinline__ BSrc src_w(const Layout& L, const MlpDesc& D, const float* P, int li, bool holey) {
+    BSrc S = src_none();
+    S.kind = SRC_W; S.p = P + D.w_off[li]; S.d2 = D.b_off[li] - D.w_off[li];
+    S.J1 = S.J = D.dout[li]; S.K = D.din[li]; S.ld = D.din[li];
+    if (holey) { S.hole0 = L.dd; S.hole = L.uoff - L.dd; }
+    return S;
+}
+
+// One MLP forward.  `in` (LDS, stride ld_in) holds the layer-0 input with a constant-1 column after its Kin0
+// columns; `holey`: the input tile is [x | pad | u | 1] and W's columns skip the pad.  head(rt, col0, acc) receives
+// the output layer's tiles.  `next`: first streamed operand of whatever product follows this MLP.
+template <int RTE, class HEAD>
+__device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const MlpDesc& D, const float* in, int ld_in, int Kin0, bool holey,
+                                        const BSrc& next, Stream& St, HEAD&& head) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const float* cur = in;
+    int ldc = ld_in;
+    for (int li = 0; li < L.L; ++li) {
+        const bool last = li == L.L - 1;
+        const BSrc S = src_w(L, D, X.P, li, holey && li == 0);
+        BSrc nx = next;
+        if (!last) nx = src_w(L, D, X.P, li + 1, false);
+        const int Kc = (li == 0 ? Kin0 : L.H) + 1;
+        MSTAMP(7);
+        const int N = D.dout[li];
+        if (last) {
+            tile_gemm<RTE>(cur, ldc, RTE, S, N, Kc, nx, St, head);
+        } else {
+            float* dst = (li & 1) ? X.h1 : X.h0;
+            float* preT = X.wsm + D.pre_off[li] + X.row0;
+            tile_gemm<RTE>(cur, ldc, RTE, S, N, Kc, nx, St, [&](int rt, int col0, const f32x4& acc) {
+                const int n = col0 + c;
+                if (n < N) {
+                    const int r0 = 16 * rt + 4 * q;
+                    *reinterpret_cast<f32x4*>(preT + (size_t)n * L.Bp + r0) = acc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(r0 + r) * L.ldh + n] = act_fwd(acc[r], L.act, L.slope);
+                }
+            });
+            cur = dst;
+            ldc = L.ldh;
+        }
+    }
+}
+
+template <int RTE>
+__global__ __launch_bounds__(NT) void k_forward(Layout L, IvaeCoef C, const float* __restrict__ params,
+                                                const float* __restrict__ x, const float* __restrict__ u,
+                                                const float* __restrict__ eps, float* __restrict__ z_out,
+                                                float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TR = L.tr, lds = L.lds;
+    float* wbuf = smem;
+    float* xin = wbuf + 2 * CHUNK;          // [x | pad | u | 1 | 0..]
+    float* h0 = xin + TR * L.ldx;
+    float* h1 = h0 + TR * L.ldh;
+    float* sg = h1 + TR * L.ldh;
+    float* sv = sg + TR * lds;
+    float* sl = sv + TR * lds;
+    float* sz = sl + TR * lds;              // z with its constant-1 column
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int model = blockIdx.y;
+    const int row0 = blockIdx.x * TR;
+    const int nrows = min(TR, L.B - row0);
+    const float* P = params + (size_t)model * L.n_params;
+    float* wsm = ws + (size_t)model * L.ws.per_model;
+    const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
+    const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
+    const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
+    const int Kx = L.uoff + L.M;            // contraction extent of the encoder's first layer (bias column index)
+
+    Stream St;
+    St.wbuf = wbuf; St.par = 0; St.n = 0;
+    MSTAMP(100);
+    const BSrc first = src_w(L, L.mlp[IVAE_MLP_G], P, 0, L.M > 0);
+    chunk_load(St.r, first, 0, 0);
+
+    for (int i = tid; i < L.smem_fwd / 4 - 2 * CHUNK; i += NT) xin[i] = 0.f;
+    __syncthreads();
+    for (int idx = tid; idx < TR * (L.dd + L.M); idx += NT) {
+        const int r = idx / (L.dd + L.M), k = idx - r * (L.dd + L.M);
+        if (r < nrows) {
+            if (k < L.dd) xin[r * L.ldx + k] = xm[(size_t)r * L.dd + k];
+            else xin[r * L.ldx + L.uoff + (k - L.dd)] = um[(size_t)r * L.M + (k - L.dd)];
+        }
+    }
+    for (int r = tid; r < TR; r += NT) {
+        xin[r * L.ldx + Kx] = 1.f;
+        if (L.L > 1) { h0[r * L.ldh + L.H] = 1.f; h1[r * L.ldh + L.H] = 1.f; }
+        sz[r * lds + L.dl] = 1.f;
+    }
+    // (the first tile_gemm's barrier orders these writes before any operand read)
+
+    FwdCtx X;
+    X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.RT = TR >> 4; X.h0 = h0; X.h1 = h1;
+    const bool has_u = L.M > 0;
+    float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
+    // one loop over the MLPs (a single inlined copy of the layer pipeline): g, logv, [logl], then f after the
+    // reparameterisation
+    for (int mi = 0; mi < 4; ++mi) {
+        const int m = mi == 0 ? IVAE_MLP_G : mi == 1 ? IVAE_MLP_LOGV : mi == 2 ? IVAE_MLP_LOGL : IVAE_MLP_F;
+        if (m == IVAE_MLP_LOGL && !has_u) {
+            for (int idx = tid; idx < TR * L.dl; idx += NT) sl[(idx / L.dl) * lds + idx % L.dl] = 1.f;
+            continue;
+        }
+        if (m == IVAE_MLP_F) {
+            __syncthreads();
+            // reparameterisation z = eps*sqrt(v) + g      (models/nets.py:301-304, 145-149)
+            for (int idx = tid; idx < TR * L.dl; idx += NT) {
+                const int r = idx / L.dl, k = idx - r * L.dl;
+                float zz = 0.f;
+                if (r < nrows) {
+                    const float e = em[(size_t)r * L.dl + k];
+                    const float vv = sv[r * lds + k], gg = sg[r * lds + k];
+                    zz = e * sqrtf(vv) + gg;
+                    const size_t o = (size_t)(row0 + r) * L.dl + k;
+                    z_out[(size_t)model * L.B * L.dl + o] = zz;
+                    wsm[L.ws.z + o] = zz;
+                    wsm[L.ws.g + o] = gg;
+                    wsm[L.ws.v + o] = vv;
+                    wsm[L.ws.l + o] = sl[r * lds + k];
+                }
+                sz[r * lds + k] = zz;
+            }
+        }
+        int mn = mi == 0 ? IVAE_MLP_LOGV : mi == 1 ? IVAE_MLP_LOGL : mi == 2 ? IVAE_MLP_F : -1;                // MLP whose first chunk is prefetched at the end
+        if (mn == IVAE_MLP_LOGL && !has_u) mn = IVAE_MLP_F;
+        BSrc next = src_none();
+        if (mn >= 0) next = src_w(L, L.mlp[mn], P, 0, has_u && mn == IVAE_MLP_LOGV);
+        const bool enc = m == IVAE_MLP_G || m == IVAE_MLP_LOGV;
+        const float* in = enc ? xin : m == IVAE_MLP_LOGL ? xin + L.uoff : sz;
+        const int ld_in = m == IVAE_MLP_F ? lds : L.ldx;
+        const int Kin0 = enc ? Kx : m == IVAE_MLP_LOGL ? L.M : L.dl;
+        float* hd = m == IVAE_MLP_G ? sg : m == IVAE_MLP_LOGV ? sv : sl;
+        const int n_out = m == IVAE_MLP_F ? L.dd : L.dl;
+        mlp_fwd<RTE>(L, X, L.mlp[m], in, ld_in, Kin0, enc && has_u, next, St, [&](int rt, int col0, const f32x4& acc) {
+            const int n = col0 + c;
+            if (n < n_out) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + 4 * q + r;
+                    if (m == IVAE_MLP_F) { if (row < nrows) fm[(size_t)row * L.dd + n] = acc[r]; }   // decoder output -> workspace
+                    else hd[row * lds + n] = m == IVAE_MLP_G ? acc[r] : expf(acc[r]);
+                }
+            }
+        });
+    }
+    MSTAMP(101);
+    __syncthreads();
+    // per-row Gaussian log-densities   (models/nets.py:306-314, 45-52)
+    if (tid < nrows) {
+        const int r = tid;
+        const float dv = C.decoder_var;
+        const float logdv = logf(dv);
+        float lpx = 0.f, lqc = 0.f, lp = 0.f;
+        for (int k = 0; k < L.dd; ++k) {
+            const float df = xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k];
+            lpx += -0.5f * (LOG2PI + logdv + df * df / dv);
+        }
+        for (int k = 0; k < L.dl; ++k) {
+            const float zz = sz[r * lds + k], gg = sg[r * lds + k], vv = sv[r * lds + k], ll = sl[r * lds + k];
+            const float dq = zz - gg;
+            lqc += -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
+            lp += -0.5f * (LOG2PI + logf(ll) + zz * zz / ll);
+        }
+        wsm[L.ws.lpx + row0 + r] = lpx;
+        wsm[L.ws.lqc + row0 + r] = lqc;
+        wsm[L.ws.lp + row0 + r] = lp;
+    }
+    MSTAMP(102);
+}
+
+// ------------------------------------------------------------------------------ backward
+struct BwdCtx {
+    const float* P;
+    const float* wsm;
+    float* slab;
+    int row0, nrows, TR;
+    float* d0;             // delta tiles, row-major (TR, ldd)
+    float* d1;
+    float* dT;             // delta transposed (n, ldr)
+};
+
+// Streamed operand of step s of an MLP's backward: s even = weight gradient of layer L-1-s/2, odd = its input gradient.
+__device__ __forceinline__ BSrc bwd_src(const Layout& L, const BwdCtx& X, const MlpDesc& D, int s, const float* in_a, int na,
+                                        const float* in_b, int nb) {
+    const int li = L.L - 1 - (s >> 1);
+    BSrc S = src_none();
+    if (s & 1) {
+        S.kind = SRC_WT; S.p = X.P + D.w_off[li]; S.J1 = S.J = D.din[li]; S.K = D.dout[li]; S.ld = D.din[li];
+    } else if (li > 0) {
+        S.kind = SRC_PRE; S.p = X.wsm + D.pre_off[li - 1] + X.row0; S.J1 = S.J = D.din[li]; S.K = X.nrows; S.ld = L.Bp;
+        S.act = L.act; S.slope = L.slope;
+    } else {
+        S.kind = SRC_ROWS; S.p = in_a; S.d2 = in_b ? in_b - in_a : 0L; S.J1 = na; S.J = na + nb; S.K = X.nrows;
+        S.ld = na; S.ld2 = nb;
+    }
+    return S;
+}
+
+// Backward of one MLP for a row tile.  On entry X.d[0] / X.dT hold dLoss/d(output) (rows >= nrows zero).  Writes
+// the tile's weight / bias gradient slab; when dx_out != null leaves dLoss/d(input) there (LDS, stride ld_dx).
+// Layer-0 input rows come from global memory: in_a (width na) followed by in_b (width nb).
+template <int RTE>
+__device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const MlpDesc& D, const float* in_a, int na, const float* in_b, int nb,
+                                        float* dx_out, int ld_dx, const BSrc& next, Stream& St) {
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int n_steps = 2 * L.L - (dx_out ? 0 : 1);
+    int cur = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        const int li = L.L - 1 - (s >> 1);
+        const int N = D.dout[li], K = D.din[li];
+        const BSrc S = bwd_src(L, X, D, s, in_a, na, in_b, nb);
+        BSrc nx = next;
+        if (s + 1 < n_steps) nx = bwd_src(L, X, D, s + 1, in_a, na, in_b, nb);
+        MSTAMP(7);
+        if (!(s & 1)) {
+            // weight gradient dW[n][k] = sum_r delta[r][n] * in[r][k]; column K of the result is the bias gradient
+            float* gW = X.slab + D.w_off[li];
+            float* gB = X.slab + D.b_off[li];
+            const int NTl = (N + 15) >> 4;
+            for (int rc = 0; rc < NTl; rc += 4) {
+                const bool more = rc + 4 < NTl;
+                BSrc nx2 = nx;
+                if (more) nx2 = S;
+                tile_gemm<4>(X.dT + rc * 16 * L.ldr, L.ldr, min(4, NTl - rc), S, K + 1, X.TR, nx2, St,
+                          [&](int rt, int col0, const f32x4& acc) {
+                              const int k = col0 + c;
+#pragma unroll
+                              for (int r = 0; r < 4; ++r) {
+                                  const int n = 16 * (rc + rt) + 4 * q + r;
+                                  if (n < N) {
+                                      if (k < K) gW[(size_t)n * K + k] = acc[r];
+                                      else if (k == K) gB[n] = acc[r];
+                                  }
+                              }
+                          });
+            }
+        } else {
+            // input gradient dX[r][k] = sum_n delta[r][n] * W[n][k]  (times act'(pre) for a hidden input)
+            const float* dcur = cur ? X.d1 : X.d0;
+            if (li > 0) {
+                float* dnx = cur ? X.d0 : X.d1;
+                const float* preT = X.wsm + D.pre_off[li - 1] + X.row0;
+                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc) {
+                    const int k = col0 + c;
+                    if (k < K) {
+                        const int r0 = 16 * rt + 4 * q;
+                        const f32x4 pre = *reinterpret_cast<const f32x4*>(preT + (size_t)k * L.Bp + r0);
+                        f32x4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            o[r] = r0 + r < X.nrows ? acc[r] * act_bwd(pre[r], L.act, L.slope) : 0.f;
+                            dnx[(r0 + r) * L.ldd + k] = o[r];
+                        }
+                        *reinterpret_cast<f32x4*>(X.dT + k * L.ldr + r0) = o;
+                    }
+                });
+                cur ^= 1;
+            } else {
+                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc) {
+                    const int k = col0 + c;
+                    if (k < K) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dx_out[(16 * rt + 4 * q + r) * ld_dx + k] = acc[r];
+                    }
+                });
+            }
+        }
+    }
+}
+
+// head delta (LDS small tile, stride lds) -> delta tile (row-major) and its transpose
+__device__ __forceinline__ void put_delta(const Layout& L, const BwdCtx& X, const float* src, int lds, int n_out) {
+    __syncthreads();       // every wave is done with the previous contents of d[0] / dT
+    for (int idx = threadIdx.x; idx < X.TR * n_out; idx += NT) {
+        const int r = idx / n_out, k = idx - r * n_out;
+        const float v = src[r * lds + k];
+        X.d0[r * L.ldd + k] = v;
+        X.dT[k * L.ldr + r] = v;
+    }
+}
+
+template <int RTE>
+__global__ __launch_bounds__(NT) void k_backward(Layout L, IvaeCoef C, const float* __restrict__ params,
+                                                 const float* __restrict__ x, const float* __restrict__ u,
+                                                 const float* __restrict__ eps, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TR = L.tr, lds = L.lds;
+    float* wbuf = smem;
+    float* dA = wbuf + 2 * CHUNK;
+    float* dB = dA + TR * L.ldd;
+    float* dT = dB + TR * L.ldd;
+    float* sdz = dT + L.nT * L.ldr;      // dLoss/dz through the decoder
+    float* sdg = sdz + TR * lds;
+    float* sdv = sdg + TR * lds;
+    float* sdl = sdv + TR * lds;
+    const int tid = threadIdx.x;
+    const int model = blockIdx.y;
+    const int row0 = blockIdx.x * TR;
+    const int nrows = min(TR, L.B - row0);
+    const float* P = params + (size_t)model * L.n_params;
+    float* wsm = ws + (size_t)model * L.ws.per_model;
+    const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
+    const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
+    const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
+    const float w = 1.f / (float)C.global_batch;
+
+    BwdCtx X;
+    X.P = P; X.wsm = wsm; X.slab = wsm + L.ws_partial + (size_t)blockIdx.x * L.n_params;
+    X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = dA; X.d1 = dB; X.dT = dT;
+    const float* zrows = wsm + L.ws.z + (size_t)row0 * L.dl;
+    const MlpDesc& DF = L.mlp[IVAE_MLP_F];
+
+    Stream St;
+    St.wbuf = wbuf; St.par = 0; St.n = 0;
+    chunk_load(St.r, bwd_src(L, X, DF, 0, zrows, L.dl, nullptr, 0), 0, 0);
+
+    for (int i = tid; i < L.smem_bwd / 4 - 2 * CHUNK; i += NT) dA[i] = 0.f;
+    __syncthreads();
+    // dLoss/df = -a*w*(x-f)/var
+    const float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
+    for (int idx = tid; idx < nrows * L.dd; idx += NT) {
+        const int r = idx / L.dd, k = idx - r * L.dd;
+        const float v = -C.a * w * (xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k]) / C.decoder_var;
+        dA[r * L.ldd + k] = v;
+        dT[k * L.ldr + r] = v;
+    }
+    // one loop over the MLPs (a single inlined copy of the layer pipeline): f, then g, logv, [logl]
+    const int n_mlp = L.M > 0 ? 4 : 3;
+    for (int mi = 0; mi < n_mlp; ++mi) {
+        const bool dec = mi == 0, pri = mi == 3;
+        const MlpDesc& D = L.mlp[dec ? IVAE_MLP_F : mi == 1 ? IVAE_MLP_G : mi == 2 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL];
+        const float* in_a = dec ? zrows : pri ? um : xm;
+        const int na = dec ? L.dl : pri ? L.M : L.dd;
+        const float* in_b = (dec || pri) ? nullptr : um;
+        const int nb = (dec || pri) ? 0 : L.M;
+        BSrc next = src_none();
+        if (mi + 1 < n_mlp) {
+            const bool npri = mi + 1 == 3;
+            next = bwd_src(L, X, L.mlp[mi + 1 == 1 ? IVAE_MLP_G : mi + 1 == 2 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL], 0, npri ? um : xm, npri ? L.M : L.dd,
+                           npri ? nullptr : um, npri ? 0 : L.M);
+        }
+        if (!dec) put_delta(L, X, mi == 1 ? sdg : mi == 2 ? sdv : sdl, lds, L.dl);
+        mlp_bwd<RTE>(L, X, D, in_a, na, in_b, nb, dec ? sdz : nullptr, lds, next, St);
+        if (dec) {
+            __syncthreads();
+            // output-layer deltas of the encoder / prior heads (SURVEY.md §8 a-bwd)
+            for (int idx = tid; idx < TR * L.dl; idx += NT) {
+                const int r = idx / L.dl, k = idx - r * L.dl;
+                float dg = 0.f, dv = 0.f, dlg = 0.f;
+                if (r < nrows) {
+                    const size_t o = (size_t)(row0 + r) * L.dl + k;
+                    const float zz = wsm[L.ws.z + o], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o], ll = wsm[L.ws.l + o];
+                    const float e = em[(size_t)r * L.dl + k];
+                    const float dq = zz - gg;
+                    const float rr = dq / vv;
+                    float Gz = sdz[r * lds + k] - w * (C.b * rr - C.d * zz / ll);
+                    dg = w * C.b * rr;
+                    dv = -w * C.b * 0.5f * (1.f - dq * dq / vv);
+                    if (C.pairwise) {
+                        Gz -= w * wsm[L.ws.rz + o];
+                        dg -= w * wsm[L.ws.cg + o];
+                        dv -= w * wsm[L.ws.cv + o];
+                    }
+                    dg += Gz;
+                    dv += Gz * 0.5f * e * sqrtf(vv);
+                    dlg = w * C.d * 0.5f * (1.f - zz * zz / ll);
+                }
+                sdg[r * lds + k] = dg;
+                sdv[r * lds + k] = dv;
+                sdl[r * lds + k] = dlg;
+            }
+        }
+    }
+}
+
+// Sum the per-tile slabs (fixed order) into grads and reduce the loss.
+__global__ __launch_bounds__(NT) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
+                                               float* __restrict__ grads, float* __restrict__ loss_out) {
+    const int model = blockIdx.y;
+    const float* wsm = ws + (size_t)model * L.ws.per_model;
+    const int nblk_p = (L.n_params + NT - 1) / NT;
+    if ((int)blockIdx.x < nblk_p) {
+        const int p = blockIdx.x * NT + threadIdx.x;
+        if (p < L.n_params) {
+            const float* s = wsm + L.ws_partial + p;
+            float acc = 0.f;
+            for (int t = 0; t < L.n_tiles; ++t) acc += s[(size_t)t * L.n_params];
+            grads[(size_t)model * L.n_params + p] = acc;
+        }
+        return;
+    }
+    if (!loss_out) return;
+    __shared__ float red[NT];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < L.B; i += NT) {
+        const float lpx = wsm[L.ws.lpx + i], lqc = wsm[L.ws.lqc + i], lp = wsm[L.ws.lp + i];
+        float row;
+        if (C.pairwise) {
+            const float lq = wsm[L.ws.lq + i], lqi = wsm[L.ws.lqi + i];
+            row = C.a * lpx - C.b * (lqc - lq) - C.c * (lq - lqi) - C.d * (lqi - lp);
+        } else {
+            row = C.a * lpx - C.b * lqc + C.d * lp;
+        }
+        acc += row;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_out[model] = -red[0] / (float)C.global_batch;
+}
+
+// ------------------------------------------------------------------------------ launchers
+static hipError_t set_smem(const void* fn, int bytes, int& cur) {
+    if (bytes <= cur) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) cur = bytes;
+    return e;
+}
+
+template <int RTE>
+static hipError_t launch_forward_t(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
+                                   const float* eps, float* z_out, float* ws, hipStream_t st) {
+    static int cur = 64 * 1024;
+    hipError_t e = set_smem((const void*)k_forward<RTE>, L.smem_fwd, cur);
+    if (e != hipSuccess) return e;
+    dim3 grid(L.n_tiles, L.n_models);
+    hipLaunchKernelGGL(k_forward<RTE>, grid, dim3(NT), L.smem_fwd, st, L, C, params, x, u, eps, z_out, ws);
+    return hipGetLastError();
+}
+
+hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
+                          const float* eps, float* z_out, float* ws, hipStream_t st) {
+    if (L.tr == 16) return launch_forward_t<1>(L, C, params, x, u, eps, z_out, ws, st);
+    if (L.tr == 32) return launch_forward_t<2>(L, C, params, x, u, eps, z_out, ws, st);
+    return launch_forward_t<4>(L, C, params, x, u, eps, z_out, ws, st);
+}
+
+template <int RTE>
+static hipError_t launch_backward_t(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
+                                    const float* eps, float* ws, hipStream_t st) {
+    static int cur = 64 * 1024;
+    hipError_t e = set_smem((const void*)k_backward<RTE>, L.smem_bwd, cur);
+    if (e != hipSuccess) return e;
+    dim3 grid(L.n_tiles, L.n_models);
+    hipLaunchKernelGGL(k_backward<RTE>, grid, dim3(NT), L.smem_bwd, st, L, C, params, x, u, eps, ws);
+    return hipGetLastError();
+}
+
+hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
+                           const float* eps, float* loss_out, float* grads, float* ws, hipStream_t st) {
+    hipError_t e = L.tr == 16 ? launch_backward_t<1>(L, C, params, x, u, eps, ws, st)
+                 : L.tr == 32 ? launch_backward_t<2>(L, C, params, x, u, eps, ws, st)
+                              : launch_backward_t<4>(L, C, params, x, u, eps, ws, st);
+    if (e != hipSuccess) return e;
+    dim3 g2((L.n_params + NT - 1) / NT + 1, L.n_models);
+    hipLaunchKernelGGL(k_reduce, g2, dim3(NT), 0, st, L, C, ws, grads, loss_out);
+    return hipGetLastError();
+}

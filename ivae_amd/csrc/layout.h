@@ -1,6 +1,7 @@
 // Parameter-arena and workspace layout shared by host launchers and kernels.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/ivae_amd.h"
 
 #define IVAE_MAX_LAYERS 8
@@ -28,10 +29,35 @@ struct Layout {
     int maxh;            // widest row among hidden / output tensors
     // workspace (float offsets per model)
     IvaeWsLayout ws;
-    int64_t ws_partial;  // (n_tiles_bwd, n_params) per-tile gradient slabs
-    int tr_fwd, tr_bwd;  // rows per workgroup
-    int n_tiles_fwd, n_tiles_bwd;
+    int64_t ws_partial;  // (n_tiles, n_params) per-tile gradient slabs
+    // row tiling of k_forward / k_backward (elbo_mfma.hip)
+    int tr, n_tiles;     // rows per workgroup (16, 32 or 64), workgroups per model
+    int Bp;              // batch rounded up to 64: leading dimension of the feature-major pre-activations
+    int uoff;            // column of u inside the [x | pad | u | 1] input tile (multiple of 4)
+    int ldx, ldh, lds;   // LDS row strides (4 * odd floats): input tile, hidden tiles, latent-width tiles
+    int ldd, ldr, nT;    // delta tiles (row-major stride), transposed delta (stride, rows)
+    int smem_fwd, smem_bwd;   // dynamic LDS bytes
 };
+
+#define IVAE_CHUNK_FLOATS (64 * 68)      // one streamed operand chunk (elbo_mfma.hip)
+#define IVAE_LDS_LIMIT (160 * 1024)
+
+static inline int ivae_up16(int x) { return (x + 15) & ~15; }
+static inline int ivae_ld4o(int x) { return (((x + 3) >> 2) | 1) << 2; }     // smallest 4*odd >= x
+
+static inline void ivae_tile_geometry(Layout& L, int tr) {
+    const int wide = L.maxh;
+    L.tr = tr;
+    L.ldx = ivae_ld4o(ivae_up16(L.uoff + L.M + 1));
+    L.ldh = ivae_ld4o(ivae_up16(L.H + 1));
+    L.lds = ivae_ld4o(ivae_up16(L.dl + 1));
+    L.ldd = ivae_ld4o(ivae_up16(wide));
+    L.nT = ivae_up16(wide);
+    L.ldr = tr + 4;
+    // +64 floats: k-steps past a tile's last column read (finite) neighbours; the last tile needs room for that
+    L.smem_fwd = 4 * (2 * IVAE_CHUNK_FLOATS + tr * L.ldx + 2 * tr * L.ldh + 4 * tr * L.lds + 64);
+    L.smem_bwd = 4 * (2 * IVAE_CHUNK_FLOATS + 2 * tr * L.ldd + L.nT * L.ldr + 4 * tr * L.lds + 64);
+}
 
 static inline int ivae_check_dims(const IvaeDims* d) {
     if (!d) return IVAE_E_NULLPTR;
@@ -52,6 +78,8 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     L.B = d->batch; L.dd = d->data_dim; L.dl = d->latent_dim; L.M = d->aux_dim;
     L.H = d->n_layers > 1 ? d->hidden_dim : 0; L.L = d->n_layers; L.act = d->activation;
     L.slope = d->slope; L.n_models = d->n_models;
+    L.Bp = (L.B + 63) & ~63;
+    L.uoff = L.M > 0 ? (L.dd + 3) & ~3 : L.dd;
     int off = 0;
     int64_t wso = 0;
     for (int m = 0; m < 4; ++m) {
@@ -67,7 +95,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
             D.dout[li] = li == L.L - 1 ? D.out_dim : L.H;
             D.w_off[li] = off; off += D.din[li] * D.dout[li];
             D.b_off[li] = off; off += D.dout[li];
-            if (li < L.L - 1) { D.pre_off[li] = wso; wso += (int64_t)L.B * L.H; }
+            if (li < L.L - 1) { D.pre_off[li] = wso; wso += (int64_t)L.Bp * L.H; }
         }
     }
     L.n_params = off;
@@ -80,14 +108,18 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     L.ws.lpx = take(L.B); L.ws.lqc = take(L.B); L.ws.lp = take(L.B); L.ws.lq = take(L.B); L.ws.lqi = take(L.B);
     L.ws.rz = take(Bl); L.ws.cg = take(Bl); L.ws.cv = take(Bl);
     L.ws.lse_s = take(L.B); L.ws.lse_k = take(Bl);
-    // rows per workgroup: keep the LDS tiles under ~60 KB
-    int ldf = L.maxw + 1, ldb = L.maxh + 1;
-    L.tr_fwd = 64; while (L.tr_fwd > 8 && (int64_t)L.tr_fwd * (3 * ldf + 4 * (L.dl + 1)) * 4 > 60 * 1024) L.tr_fwd >>= 1;
-    L.tr_bwd = 64; while (L.tr_bwd > 8 && (int64_t)L.tr_bwd * (3 * ldb + 4 * (L.dl + 1)) * 4 > 60 * 1024) L.tr_bwd >>= 1;
-    if ((int64_t)L.tr_fwd * (3 * ldf + 4 * (L.dl + 1)) * 4 > 60 * 1024) return IVAE_E_TOOLARGE;
-    L.n_tiles_fwd = (L.B + L.tr_fwd - 1) / L.tr_fwd;
-    L.n_tiles_bwd = (L.B + L.tr_bwd - 1) / L.tr_bwd;
-    L.ws_partial = take((int64_t)L.n_tiles_bwd * L.n_params);
+    // rows per workgroup: the largest of 64/32/16 that still gives the 256 CUs a workgroup each and fits the LDS
+    int tr = 64;
+    while (tr > 16 && (int64_t)((L.B + tr - 1) / tr) * L.n_models < 256) tr >>= 1;
+    if (const char* e = getenv("IVAE_AMD_TILE_ROWS")) {          // tuning knob: 16, 32 or 64
+        const int v = atoi(e);
+        if (v == 16 || v == 32 || v == 64) tr = v;
+    }
+    ivae_tile_geometry(L, tr);
+    while (tr > 16 && (L.smem_fwd > IVAE_LDS_LIMIT || L.smem_bwd > IVAE_LDS_LIMIT)) { tr >>= 1; ivae_tile_geometry(L, tr); }
+    if (L.smem_fwd > IVAE_LDS_LIMIT || L.smem_bwd > IVAE_LDS_LIMIT) return IVAE_E_TOOLARGE;
+    L.n_tiles = (L.B + tr - 1) / tr;
+    L.ws_partial = take((int64_t)L.n_tiles * L.n_params);
     wso = (wso + 63) & ~(int64_t)63;
     L.ws.per_model = wso;
     return IVAE_OK;
