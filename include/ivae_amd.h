@@ -110,11 +110,15 @@ int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params
 /* Pairwise log q(z_i | x_j) statistics and their gradient terms, never materialising the
  * (B,B,d) tensor of models/nets.py:180-182, 466-469.  Rows i: z (n_rows, d) of this shard.
  * Columns j: g_cols, v_cols (n_cols, d) of the GLOBAL batch.  Writes lq, lqi, rz (n_rows,*)
- * and cg, cv (n_cols, d) (column sums over this shard's rows).  Single model only. */
+ * and cg, cv (n_cols, d) (column sums over this shard's rows).  Single model only.
+ * workspace: at least ivae_pairwise_workspace_bytes(n_rows, n_cols, latent_dim) bytes of caller-owned
+ * scratch (per-slice log-sum-exp statistics and gradient partial sums, merged in a fixed order). */
+int ivae_pairwise_workspace_bytes(int32_t n_rows, int32_t n_cols, int32_t latent_dim, size_t* out);
 int ivae_pairwise(int32_t n_rows, int32_t n_cols, int32_t latent_dim, const IvaeCoef* coef,
                   const float* z, const float* g_cols, const float* v_cols,
                   float* lq, float* lqi, float* lse_s, float* lse_k,
-                  float* rz, float* cg, float* cv, void* stream);
+                  float* rz, float* cg, float* cv,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of everything ivae_forward (+ ivae_pairwise) computed; autograd at
  * runners/ivae.py:82, models/wrappers.py:69. */

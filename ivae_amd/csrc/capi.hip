@@ -66,15 +66,26 @@ int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_forward");
 }
 
+int ivae_pairwise_workspace_bytes(int32_t n_rows, int32_t n_cols, int32_t latent_dim, size_t* out) {
+    if (!out) return IVAE_E_NULLPTR;
+    if (n_rows <= 0 || n_cols <= 0 || latent_dim <= 0) return IVAE_E_BADDIMS;
+    if (latent_dim > 64) return IVAE_E_TOOLARGE;
+    *out = pairwise_ws_floats(n_rows, n_cols, latent_dim) * sizeof(float);
+    return IVAE_OK;
+}
+
 int ivae_pairwise(int32_t n_rows, int32_t n_cols, int32_t latent_dim, const IvaeCoef* coef, const float* z,
                   const float* g_cols, const float* v_cols, float* lq, float* lqi, float* lse_s, float* lse_k,
-                  float* rz, float* cg, float* cv, void* stream) {
+                  float* rz, float* cg, float* cv, void* workspace, size_t workspace_bytes, void* stream) {
     if (n_rows <= 0 || n_cols <= 0 || latent_dim <= 0) return IVAE_E_BADDIMS;
     if (latent_dim > 64) return IVAE_E_TOOLARGE;
     if (!coef || !z || !g_cols || !v_cols || !lq || !lqi || !lse_s || !lse_k || !rz || !cg || !cv) return IVAE_E_NULLPTR;
     if (!(coef->dataset_size > 0.f) || coef->global_batch <= 0) return IVAE_E_BADDIMS;
+    const size_t need = pairwise_ws_floats(n_rows, n_cols, latent_dim) * sizeof(float);
+    if (need > 0 && !workspace) return IVAE_E_NULLPTR;
+    if (workspace_bytes < need) return IVAE_E_WORKSPACE;
     hipError_t e = launch_pairwise(n_rows, n_cols, latent_dim, *coef, z, g_cols, v_cols, lq, lqi, lse_s, lse_k, rz, cg,
-                                   cv, (hipStream_t)stream);
+                                   cv, (float*)workspace, (hipStream_t)stream);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_pairwise");
 }
 
@@ -103,7 +114,8 @@ int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* p
         for (int m = 0; m < L.n_models; ++m) {
             float* w = (float*)workspace + (size_t)m * L.ws.per_model;
             rc = ivae_pairwise(L.B, L.B, L.dl, coef, w + L.ws.z, w + L.ws.g, w + L.ws.v, w + L.ws.lq, w + L.ws.lqi,
-                               w + L.ws.lse_s, w + L.ws.lse_k, w + L.ws.rz, w + L.ws.cg, w + L.ws.cv, stream);
+                               w + L.ws.lse_s, w + L.ws.lse_k, w + L.ws.rz, w + L.ws.cg, w + L.ws.cv, w + L.ws_pair,
+                               pairwise_ws_floats(L.B, L.B, L.dl) * sizeof(float), stream);
             if (rc) return rc;
         }
     }

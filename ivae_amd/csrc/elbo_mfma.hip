@@ -647,24 +647,37 @@ __global__ __launch_bounds__(NT) void k_backward(Layout L, IvaeCoef C, const flo
     }
 }
 
-// Sum the per-tile slabs (fixed order) into grads and reduce the loss.
+// Sum the per-tile slabs into grads and reduce the loss.  A block sums 64 parameters: wave g adds the tiles
+// t = g, g+4, ... with four independent accumulators (loads in flight), then the partials are combined in a fixed
+// order, so the result does not depend on scheduling.
+#define RED_P 64
 __global__ __launch_bounds__(NT) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
                                                float* __restrict__ grads, float* __restrict__ loss_out) {
     const int model = blockIdx.y;
     const float* wsm = ws + (size_t)model * L.ws.per_model;
-    const int nblk_p = (L.n_params + NT - 1) / NT;
+    const int nblk_p = (L.n_params + RED_P - 1) / RED_P;
+    __shared__ float red[NT];
     if ((int)blockIdx.x < nblk_p) {
-        const int p = blockIdx.x * NT + threadIdx.x;
-        if (p < L.n_params) {
-            const float* s = wsm + L.ws_partial + p;
-            float acc = 0.f;
-            for (int t = 0; t < L.n_tiles; ++t) acc += s[(size_t)t * L.n_params];
-            grads[(size_t)model * L.n_params + p] = acc;
+        const int p = min((int)blockIdx.x * RED_P + (int)(threadIdx.x & 63), L.n_params - 1);
+        const int g = threadIdx.x >> 6;
+        const float* s = wsm + L.ws_partial + p;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int t = g;
+        for (; t + 12 < L.n_tiles; t += 16) {
+            a0 += s[(size_t)t * L.n_params];
+            a1 += s[(size_t)(t + 4) * L.n_params];
+            a2 += s[(size_t)(t + 8) * L.n_params];
+            a3 += s[(size_t)(t + 12) * L.n_params];
         }
+        for (; t < L.n_tiles; t += 4) a0 += s[(size_t)t * L.n_params];
+        red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (g == 0 && (int)blockIdx.x * RED_P + (int)threadIdx.x < L.n_params)
+            grads[(size_t)model * L.n_params + p] = (red[threadIdx.x] + red[threadIdx.x + 64]) +
+                                                    (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
         return;
     }
     if (!loss_out) return;
-    __shared__ float red[NT];
     float acc = 0.f;
     for (int i = threadIdx.x; i < L.B; i += NT) {
         const float lpx = wsm[L.ws.lpx + i], lqc = wsm[L.ws.lqc + i], lp = wsm[L.ws.lp + i];
@@ -729,7 +742,7 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
                  : L.tr == 32 ? launch_backward_t<2>(L, C, params, x, u, eps, ws, st)
                               : launch_backward_t<4>(L, C, params, x, u, eps, ws, st);
     if (e != hipSuccess) return e;
-    dim3 g2((L.n_params + NT - 1) / NT + 1, L.n_models);
+    dim3 g2((L.n_params + RED_P - 1) / RED_P + 1, L.n_models);
     hipLaunchKernelGGL(k_reduce, g2, dim3(NT), 0, st, L, C, ws, grads, loss_out);
     return hipGetLastError();
 }

@@ -10,6 +10,9 @@
 #define IVAE_MLP_G 2
 #define IVAE_MLP_LOGV 3
 
+size_t pairwise_ws_floats(int n_rows, int n_cols, int d);     // pairwise.hip
+static inline size_t ivae_pair_ws_floats(int n_rows, int n_cols, int d) { return pairwise_ws_floats(n_rows, n_cols, d); }
+
 struct MlpDesc {
     int present;
     int in_dim, out_dim;
@@ -30,6 +33,7 @@ struct Layout {
     // workspace (float offsets per model)
     IvaeWsLayout ws;
     int64_t ws_partial;  // (n_tiles, n_params) per-tile gradient slabs
+    int64_t ws_pair;     // scratch of the pairwise kernels for a (B, B, dl) problem
     // row tiling of k_forward / k_backward (elbo_mfma.hip)
     int tr, n_tiles;     // rows per workgroup (16, 32 or 64), workgroups per model
     int Bp;              // batch rounded up to 64: leading dimension of the feature-major pre-activations
@@ -120,6 +124,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     if (L.smem_fwd > IVAE_LDS_LIMIT || L.smem_bwd > IVAE_LDS_LIMIT) return IVAE_E_TOOLARGE;
     L.n_tiles = (L.B + tr - 1) / tr;
     L.ws_partial = take((int64_t)L.n_tiles * L.n_params);
+    L.ws_pair = take((int64_t)ivae_pair_ws_floats(L.B, L.B, L.dl));
     wso = (wso + 63) & ~(int64_t)63;
     L.ws.per_model = wso;
     return IVAE_OK;

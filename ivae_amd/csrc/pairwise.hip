@@ -1,21 +1,299 @@
 // Pairwise log q(z_i | x_j) kernels for the total-correlation decomposition.
 //
-// Reference (models/nets.py:180-182, 238-240, 466-469) materialises T[i,j,k] =
-// log N(z_ik; g_jk, v_jk) as a (B,B,d) tensor plus autograd copies.  Here T is never stored:
-// one 64-lane wavefront owns a row i (k_pair_rows) or a column j (k_pair_cols), its lanes
-// stride over the other index, and the log-sum-exp statistics are combined with wavefront
-// shuffles (online max/sum, flash-attention style).  Outputs:
+// Reference (models/nets.py:180-182, 238-240, 466-469) materialises T[i,j,k] = log N(z_ik; g_jk, v_jk) as a
+// (B,B,d) tensor plus autograd copies.  Here T is never stored.  Outputs:
 //   lse_s[i]   = LSE_j sum_k T        lse_k[i,k] = LSE_j T[.,.,k]
 //   lq[i]      = lse_s - log(M*N)     lqi[i]     = sum_k (lse_k - log(M*N))
 //   rz[i,k]    = sum_j Wt * dT/dz_ik           Wt = (b-c) softmax_j(sum_k T) + (c-d) softmax_j(T_k)
 //   cg[j,k]    = sum_i Wt * dT/dg_jk           cv[j,k] = sum_i Wt * dT/dlogv_jk
+//
+// Layout of the work (d <= 32): a LANE owns a row i (64 rows per wave, 256 per workgroup) and walks over a slice of
+// columns j whose per-column constants  g_jk, w_jk = 1/v_jk, a_jk = -(log 2pi + log v_jk)/2  were computed once per
+// workgroup into LDS, so that  T = a - (z-g)^2 w / 2  costs three VALU operations with wave-uniform (broadcast)
+// operands: no logarithm or division per (i,j,k), no cross-lane reduction at all.  The column range is split into
+// slices over blockIdx.y to fill the chip; the per-slice log-sum-exp statistics (max, sum) and gradient partial sums
+// go to a caller-provided workspace and are merged in a fixed order (deterministic results).  The column gradients
+// cg, cv use the mirrored map (a lane owns a column, walks over a slice of rows).  Four launches:
+//   k_pair_stats -> k_pair_combine -> k_pair_grads (both roles) -> k_pair_finish (+ lq, lqi)
+// exp() inside the sums is v_exp_f32 (exp2(x log2 e)): arguments are <= 0 and the terms that matter have small
+// magnitude, so the sums keep ~1e-6 relative accuracy; the final log / merge steps use the full-precision functions.
+// 32 < d <= 64 takes the wave-per-row kernels at the end of this file.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "kernels.h"
 
 #define LOG2PI 1.8378770664093453f
 #define NEG_BIG -3.0e38f
+#define PB 256                     // rows (columns) per workgroup: one per lane
 
+struct PairGeom {                  // host-computed slicing (pair_geometry)
+    int n_rows, n_cols, d, dp;     // dp: d rounded up to a multiple of 4 (row stride of the staged constants)
+    int CS, NS;                    // columns per slice, slices        (stats, row gradients)
+    int RS, NR;                    // rows per slice, slices           (column gradients)
+    size_t o_pm, o_ps;             // (NS, d+1, n_rows) per-slice max / sum (log2 units); plane d: the sum-over-k statistic
+    size_t o_rz;                   // (NS, d, n_rows)
+    size_t o_cg, o_cv;             // (NR, d, n_cols)
+    size_t total;                  // floats
+};
+
+static PairGeom pair_geometry(int n_rows, int n_cols, int d) {
+    PairGeom G;
+    G.n_rows = n_rows; G.n_cols = n_cols; G.d = d; G.dp = (d + 3) & ~3;
+    const int rb = (n_rows + PB - 1) / PB, cb = (n_cols + PB - 1) / PB;
+    // slices: enough workgroups for the 256 CUs (x2), bounded by 48 KB of LDS for the staged constants
+    int want = (512 + rb - 1) / rb;
+    G.CS = (n_cols + want - 1) / want;
+    if (G.CS < 32) G.CS = 32;
+    if (G.CS > 4096 / G.dp) G.CS = 4096 / G.dp;
+    G.NS = (n_cols + G.CS - 1) / G.CS;
+    want = (512 + cb - 1) / cb;
+    G.RS = (n_rows + want - 1) / want;
+    if (G.RS < 32) G.RS = 32;
+    if (G.RS > 12288 / (2 * G.dp + 1)) G.RS = 12288 / (2 * G.dp + 1);
+    G.NR = (n_rows + G.RS - 1) / G.RS;
+    size_t o = 0;
+    G.o_pm = o; o += (size_t)G.NS * (d + 1) * n_rows;
+    G.o_ps = o; o += (size_t)G.NS * (d + 1) * n_rows;
+    G.o_rz = o; o += (size_t)G.NS * d * n_rows;
+    G.o_cg = o; o += (size_t)G.NR * d * n_cols;
+    G.o_cv = o; o += (size_t)G.NR * d * n_cols;
+    G.total = o;
+    return G;
+}
+
+size_t pairwise_ws_floats(int n_rows, int n_cols, int d) {
+    if (d > 32) return 0;
+    return pair_geometry(n_rows, n_cols, d).total;
+}
+
+// The inner loops work in log2 units: T2 = T * log2(e) = A2 - dq^2 * W2 with A2 = a * log2(e), W2 = w * log2(e) / 2,
+// so that exp(T - m) is one v_exp_f32 of a difference.  Padded k (d <= k < DP) carry A2 = W2 = 0, z = g = 0: T2 = 0,
+// which adds nothing to the sum over k; their own statistics are never read.
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Column constants of slice [j0, j0+nj) -> LDS, three (nj, DP) arrays.
+template <int DP>
+__device__ __forceinline__ void stage_cols(const float* __restrict__ g, const float* __restrict__ v, int j0, int nj, int d,
+                                           float* G, float* W2, float* A2) {
+    for (int e = threadIdx.x; e < nj * DP; e += PB) {
+        const int j = e / DP, k = e - j * DP;
+        float gg = 0.f, w2 = 0.f, a2 = 0.f;
+        if (k < d) {
+            const float vv = v[(size_t)(j0 + j) * d + k];
+            gg = g[(size_t)(j0 + j) * d + k];
+            w2 = (0.5f * LOG2E) / vv;
+            a2 = (-0.5f * LOG2E) * (LOG2PI + logf(vv));
+        }
+        G[e] = gg; W2[e] = w2; A2[e] = a2;
+    }
+}
+
+// Per-slice statistics: max and sum-of-exp2 over the slice's columns, for every k and for the sum over k.
+template <int DP>
+__global__ __launch_bounds__(PB) void k_pair_stats(PairGeom P, const float* __restrict__ z, const float* __restrict__ g,
+                                                   const float* __restrict__ v, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int d = P.d, sl = blockIdx.y, j0 = sl * P.CS, nj = min(P.CS, P.n_cols - j0);
+    float* G = sm; float* W2 = G + P.CS * DP; float* A2 = W2 + P.CS * DP;
+    stage_cols<DP>(g, v, j0, nj, d, G, W2, A2);
+    __syncthreads();
+    const int i = blockIdx.x * PB + threadIdx.x;
+    const int ic = min(i, P.n_rows - 1);
+    float zi[DP], m[DP], s[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) { zi[k] = k < d ? z[(size_t)ic * d + k] : 0.f; m[k] = NEG_BIG; s[k] = 0.f; }
+    float mS = NEG_BIG, sS = 0.f;
+    for (int j = 0; j < nj; ++j) {
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const float dq = zi[k] - G[j * DP + k];
+            const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
+            m[k] = fmaxf(m[k], t);
+            S += t;
+        }
+        mS = fmaxf(mS, S);
+    }
+    for (int j = 0; j < nj; ++j) {
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const float dq = zi[k] - G[j * DP + k];
+            const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
+            s[k] += fexp2(t - m[k]);
+            S += t;
+        }
+        sS += fexp2(S - mS);
+    }
+    if (i < P.n_rows) {
+        float* pm = ws + P.o_pm + (size_t)sl * (d + 1) * P.n_rows + i;
+        float* ps = ws + P.o_ps + (size_t)sl * (d + 1) * P.n_rows + i;
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+            if (k < d) { pm[(size_t)k * P.n_rows] = m[k]; ps[(size_t)k * P.n_rows] = s[k]; }
+        pm[(size_t)d * P.n_rows] = mS;
+        ps[(size_t)d * P.n_rows] = sS;
+    }
+}
+
+// Merge the slices (log2 units in, natural-log LSE out): thread = (plane k <= d, row i).
+__global__ __launch_bounds__(PB) void k_pair_combine(PairGeom P, const float* __restrict__ ws,
+                                                     float* __restrict__ lse_s, float* __restrict__ lse_k) {
+    const int i = blockIdx.x * PB + threadIdx.x, k = blockIdx.y;
+    if (i >= P.n_rows) return;
+    const size_t plane = (size_t)(P.d + 1) * P.n_rows, at = (size_t)k * P.n_rows + i;
+    const float* pm = ws + P.o_pm + at;
+    const float* ps = ws + P.o_ps + at;
+    float M = NEG_BIG;
+#pragma unroll 8
+    for (int sl = 0; sl < P.NS; ++sl) M = fmaxf(M, pm[sl * plane]);
+    float s = 0.f;
+#pragma unroll 8
+    for (int sl = 0; sl < P.NS; ++sl) s += ps[sl * plane] * exp2f(pm[sl * plane] - M);
+    const float lse = M * LN2 + logf(s);
+    if (k == P.d) lse_s[i] = lse;
+    else lse_k[(size_t)i * P.d + k] = lse;
+}
+
+// Gradient partial sums.  blockIdx.z == 0: row role (lane = row i, slice of columns) -> rz partials;
+// blockIdx.z == 1: column role (lane = column j, slice of rows) -> cg, cv partials.
+template <int DP>
+__global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const float* __restrict__ z,
+                                                   const float* __restrict__ g, const float* __restrict__ v,
+                                                   const float* __restrict__ lse_s, const float* __restrict__ lse_k,
+                                                   float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int d = P.d;
+    const float cP = C.b - C.c, cQ = C.c - C.d;
+    if (blockIdx.z == 0) {
+        if ((int)blockIdx.x * PB >= P.n_rows || (int)blockIdx.y >= P.NS) return;
+        const int sl = blockIdx.y, j0 = sl * P.CS, nj = min(P.CS, P.n_cols - j0);
+        float* G = sm; float* W2 = G + P.CS * DP; float* A2 = W2 + P.CS * DP;
+        stage_cols<DP>(g, v, j0, nj, d, G, W2, A2);
+        __syncthreads();
+        const int i = blockIdx.x * PB + threadIdx.x;
+        const int ic = min(i, P.n_rows - 1);
+        float zi[DP], lk[DP], acc[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            zi[k] = k < d ? z[(size_t)ic * d + k] : 0.f;
+            lk[k] = k < d ? lse_k[(size_t)ic * d + k] * LOG2E : 0.f;
+            acc[k] = 0.f;
+        }
+        const float LS = lse_s[ic] * LOG2E;
+        for (int j = 0; j < nj; ++j) {
+            float tt[DP], rr[DP];
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float dq = zi[k] - G[j * DP + k];
+                rr[k] = dq * W2[j * DP + k];                       // (z - g) / v * log2(e) / 2
+                tt[k] = A2[j * DP + k] - dq * rr[k];
+                S += tt[k];
+            }
+            const float Pij = cP * fexp2(S - LS);
+#pragma unroll
+            for (int k = 0; k < DP; ++k) acc[k] -= (Pij + cQ * fexp2(tt[k] - lk[k])) * rr[k];
+        }
+        if (i < P.n_rows) {
+            float* pr = ws + P.o_rz + (size_t)sl * d * P.n_rows + i;
+#pragma unroll
+            for (int k = 0; k < DP; ++k)
+                if (k < d) pr[(size_t)k * P.n_rows] = acc[k] * (2.f * LN2);
+        }
+    } else {
+        if ((int)blockIdx.x * PB >= P.n_cols || (int)blockIdx.y >= P.NR) return;
+        const int rs = blockIdx.y, i0 = rs * P.RS, ni = min(P.RS, P.n_rows - i0);
+        float* Z = sm; float* LK = Z + P.RS * DP; float* LSs = LK + P.RS * DP;
+        for (int e = threadIdx.x; e < ni * DP; e += PB) {
+            const int i = e / DP, k = e - i * DP;
+            Z[e] = k < d ? z[(size_t)(i0 + i) * d + k] : 0.f;
+            LK[e] = k < d ? lse_k[(size_t)(i0 + i) * d + k] * LOG2E : 0.f;
+        }
+        for (int e = threadIdx.x; e < ni; e += PB) LSs[e] = lse_s[i0 + e] * LOG2E;
+        __syncthreads();
+        const int j = blockIdx.x * PB + threadIdx.x;
+        const int jc = min(j, P.n_cols - 1);
+        float gj[DP], wj[DP], aj[DP], ag[DP], av[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const float vv = k < d ? v[(size_t)jc * d + k] : 1.f;
+            gj[k] = k < d ? g[(size_t)jc * d + k] : 0.f;
+            wj[k] = k < d ? (0.5f * LOG2E) / vv : 0.f;
+            aj[k] = k < d ? (-0.5f * LOG2E) * (LOG2PI + logf(vv)) : 0.f;
+            ag[k] = 0.f; av[k] = 0.f;
+        }
+        for (int i = 0; i < ni; ++i) {
+            float tt[DP], rr[DP];
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float dq = Z[i * DP + k] - gj[k];
+                rr[k] = dq * wj[k];
+                tt[k] = aj[k] - dq * rr[k];
+                S += tt[k];
+            }
+            const float Pij = cP * fexp2(S - LSs[i]);
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float wt = Pij + cQ * fexp2(tt[k] - LK[i * DP + k]);
+                ag[k] += wt * rr[k];
+                av[k] -= wt * (0.5f + LN2 * (tt[k] - aj[k]));      // -1/2 (1 - dq^2 / v),  dq^2 / v = -2 ln2 (T2 - A2)
+            }
+        }
+        if (j < P.n_cols) {
+            float* pg = ws + P.o_cg + (size_t)rs * d * P.n_cols + j;
+            float* pv = ws + P.o_cv + (size_t)rs * d * P.n_cols + j;
+#pragma unroll
+            for (int k = 0; k < DP; ++k)
+                if (k < d) { pg[(size_t)k * P.n_cols] = ag[k] * (2.f * LN2); pv[(size_t)k * P.n_cols] = av[k]; }
+        }
+    }
+}
+
+// Fixed-order sums of the gradient partials: thread = (k, row or column); blockIdx.z: 0 rz (+ lq, lqi), 1 cg, 2 cv.
+__global__ __launch_bounds__(PB) void k_pair_finish(PairGeom P, float logMN, const float* __restrict__ ws,
+                                                    const float* __restrict__ lse_s, const float* __restrict__ lse_k,
+                                                    float* __restrict__ lq, float* __restrict__ lqi, float* __restrict__ rz,
+                                                    float* __restrict__ cg, float* __restrict__ cv) {
+    const int which = blockIdx.z, k = blockIdx.y;
+    const int n = which == 0 ? P.n_rows : P.n_cols, ns = which == 0 ? P.NS : P.NR;
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0 && k == 0) {          // lq, lqi of row i from the merged statistics
+        float acc = 0.f;
+        for (int kk = 0; kk < P.d; ++kk) acc += lse_k[(size_t)i * P.d + kk] - logMN;
+        lq[i] = lse_s[i] - logMN;
+        lqi[i] = acc;
+    }
+    const float* src = ws + (which == 0 ? P.o_rz : which == 1 ? P.o_cg : P.o_cv) + (size_t)k * n + i;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < ns; ++s) acc += src[(size_t)s * P.d * n];
+    float* dst = which == 0 ? rz : which == 1 ? cg : cv;
+    dst[(size_t)i * P.d + k] = acc;
+}
+
+template <int DP>
+static hipError_t launch_sliced(const PairGeom& P, const IvaeCoef& C, float logMN, const float* z, const float* g,
+                                const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz, float* cg,
+                                float* cv, float* ws, hipStream_t st) {
+    const int d = P.d;
+    const int rb = (P.n_rows + PB - 1) / PB, cb = (P.n_cols + PB - 1) / PB;
+    const size_t sm_cols = (size_t)3 * P.CS * DP * sizeof(float);
+    const size_t sm_rows = (size_t)(2 * P.RS * DP + P.RS) * sizeof(float);
+    hipLaunchKernelGGL(k_pair_stats<DP>, dim3(rb, P.NS), dim3(PB), sm_cols, st, P, z, g, v, ws);
+    hipLaunchKernelGGL(k_pair_combine, dim3(rb, d + 1), dim3(PB), 0, st, P, ws, lse_s, lse_k);
+    const int gx = rb > cb ? rb : cb, gy = P.NS > P.NR ? P.NS : P.NR;
+    hipLaunchKernelGGL(k_pair_grads<DP>, dim3(gx, gy, 2), dim3(PB), sm_cols > sm_rows ? sm_cols : sm_rows, st, P, C, z, g, v,
+                       lse_s, lse_k, ws);
+    hipLaunchKernelGGL(k_pair_finish, dim3(gx, d, 3), dim3(PB), 0, st, P, logMN, ws, lse_s, lse_k, lq, lqi, rz, cg, cv);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ 32 < d <= 64: one wavefront per row / column
 __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
     const float mn = fmaxf(m, m2);
     s = s * expf(m - mn) + s2 * expf(m2 - mn);
@@ -27,12 +305,12 @@ __device__ __forceinline__ void lse_push(float& m, float& s, float t) {
     else s += expf(t - m);
 }
 
-template <int DMAX>
-__global__ __launch_bounds__(256) void k_pair_rows(int n_rows, int n_cols, int d, IvaeCoef C, float logMN,
-                                                   const float* __restrict__ z, const float* __restrict__ g,
-                                                   const float* __restrict__ v, float* __restrict__ lq,
-                                                   float* __restrict__ lqi, float* __restrict__ lse_s,
-                                                   float* __restrict__ lse_k, float* __restrict__ rz) {
+__global__ __launch_bounds__(256) void k_pair_rows_wide(int n_rows, int n_cols, int d, IvaeCoef C, float logMN,
+                                                        const float* __restrict__ z, const float* __restrict__ g,
+                                                        const float* __restrict__ v, float* __restrict__ lq,
+                                                        float* __restrict__ lqi, float* __restrict__ lse_s,
+                                                        float* __restrict__ lse_k, float* __restrict__ rz) {
+    constexpr int DMAX = 64;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_rows) return;            // wave-uniform exit
@@ -71,7 +349,6 @@ __global__ __launch_bounds__(256) void k_pair_rows(int n_rows, int n_cols, int d
         if (k < d) { mk[k] = mk[k] + logf(sk[k]); lqi_acc += mk[k] - logMN; }   // mk now holds lse_k
     }
     if (lane == 0) { lse_s[i] = LS; lq[i] = LS - logMN; lqi[i] = lqi_acc; }
-    // second sweep: row gradient term
     const float cP = C.b - C.c, cQ = C.c - C.d;
     float acc[DMAX];
 #pragma unroll
@@ -105,12 +382,12 @@ __global__ __launch_bounds__(256) void k_pair_rows(int n_rows, int n_cols, int d
     }
 }
 
-template <int DMAX>
-__global__ __launch_bounds__(256) void k_pair_cols(int n_rows, int n_cols, int d, IvaeCoef C,
-                                                   const float* __restrict__ z, const float* __restrict__ g,
-                                                   const float* __restrict__ v, const float* __restrict__ lse_s,
-                                                   const float* __restrict__ lse_k, float* __restrict__ cg,
-                                                   float* __restrict__ cv) {
+__global__ __launch_bounds__(256) void k_pair_cols_wide(int n_rows, int n_cols, int d, IvaeCoef C,
+                                                        const float* __restrict__ z, const float* __restrict__ g,
+                                                        const float* __restrict__ v, const float* __restrict__ lse_s,
+                                                        const float* __restrict__ lse_k, float* __restrict__ cg,
+                                                        float* __restrict__ cv) {
+    constexpr int DMAX = 64;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_cols) return;
@@ -156,25 +433,22 @@ __global__ __launch_bounds__(256) void k_pair_cols(int n_rows, int n_cols, int d
     }
 }
 
-template <int DMAX>
-static hipError_t launch_t(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
-                           const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
-                           float* cg, float* cv, hipStream_t st) {
-    const float logMN = (float)log((double)C.global_batch * (double)C.dataset_size);   // np.log(M * N), nets.py:181
-    hipLaunchKernelGGL(k_pair_rows<DMAX>, dim3((n_rows + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, logMN, z, g, v,
-                       lq, lqi, lse_s, lse_k, rz);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pair_cols<DMAX>, dim3((n_cols + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, z, g, v,
-                       lse_s, lse_k, cg, cv);
-    return hipGetLastError();
-}
-
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
                            const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
-                           float* cg, float* cv, hipStream_t st) {
-    if (d <= 8) return launch_t<8>(n_rows, n_cols, d, C, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, st);
-    if (d <= 16) return launch_t<16>(n_rows, n_cols, d, C, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, st);
-    if (d <= 32) return launch_t<32>(n_rows, n_cols, d, C, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, st);
-    return launch_t<64>(n_rows, n_cols, d, C, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, st);
+                           float* cg, float* cv, float* ws, hipStream_t st) {
+    const float logMN = (float)log((double)C.global_batch * (double)C.dataset_size);   // np.log(M * N), nets.py:181
+    if (d > 32) {
+        hipLaunchKernelGGL(k_pair_rows_wide, dim3((n_rows + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, logMN, z, g, v,
+                           lq, lqi, lse_s, lse_k, rz);
+        hipLaunchKernelGGL(k_pair_cols_wide, dim3((n_cols + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, z, g, v,
+                           lse_s, lse_k, cg, cv);
+        return hipGetLastError();
+    }
+    const PairGeom P = pair_geometry(n_rows, n_cols, d);
+#define PAIR_CASE(DP_) case DP_: return launch_sliced<DP_>(P, C, logMN, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, ws, st);
+    switch (P.dp) {
+        PAIR_CASE(4) PAIR_CASE(8) PAIR_CASE(12) PAIR_CASE(16) PAIR_CASE(20) PAIR_CASE(24) PAIR_CASE(28) PAIR_CASE(32)
+    }
+#undef PAIR_CASE
+    return hipErrorInvalidValue;
 }

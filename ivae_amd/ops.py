@@ -152,11 +152,14 @@ def pairwise(coef, z, g_cols, v_cols):
     mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     out = dict(lq=mk(n_rows), lqi=mk(n_rows), lse_s=mk(n_rows), lse_k=mk(n_rows, d), rz=mk(n_rows, d),
                cg=mk(n_cols, d), cv=mk(n_cols, d))
+    nb = C.c_size_t()
+    check(_lib.lib().ivae_pairwise_workspace_bytes(n_rows, n_cols, d, C.byref(nb)), "ivae_pairwise_workspace_bytes")
     with torch.cuda.device(dev):
+        scratch = mk(max(1, (nb.value + 3) // 4))
         check(_lib.lib().ivae_pairwise(n_rows, n_cols, d, C.byref(coef), _ptr(z), _ptr(g_cols), _ptr(v_cols),
                                        _ptr(out["lq"]), _ptr(out["lqi"]), _ptr(out["lse_s"]), _ptr(out["lse_k"]),
-                                       _ptr(out["rz"]), _ptr(out["cg"]), _ptr(out["cv"]), _stream(dev)),
-              "ivae_pairwise")
+                                       _ptr(out["rz"]), _ptr(out["cg"]), _ptr(out["cv"]), _ptr(scratch),
+                                       scratch.numel() * 4, _stream(dev)), "ivae_pairwise")
     return out
 
 
