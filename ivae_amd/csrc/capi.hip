@@ -62,7 +62,7 @@ int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params
     if ((rc = check_coef(dims, coef))) return rc;
     if (!params || !x || !eps || !z_out || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
     if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
-    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, (hipStream_t)stream);
+    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, false, (hipStream_t)stream);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_forward");
 }
 
@@ -98,19 +98,24 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
     if ((rc = check_coef(dims, coef))) return rc;
     if (!params || !x || !eps || !grads || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
     if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
-    hipError_t e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, (hipStream_t)stream);
+    hipError_t e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, false, (hipStream_t)stream);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_backward");
 }
 
 int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
                       const float* eps, float* z_out, float* loss_out, float* grads, void* workspace,
                       size_t workspace_bytes, void* stream) {
-    int rc = ivae_forward(dims, coef, params, x, u, eps, z_out, workspace, workspace_bytes, stream);
+    Layout L;
+    int rc = ivae_make_layout(dims, &L);
     if (rc) return rc;
+    if ((rc = check_coef(dims, coef))) return rc;
+    if (!params || !x || !eps || !z_out || !grads || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
+    if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
+    if (coef->pairwise && coef->global_batch != dims->batch) return IVAE_E_BADDIMS;   // DP callers run the phases themselves
+    // the decoder's backward rides in the decoder's forward launch (it needs nothing from other rows)
+    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, true, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "ivae_elbo_fwd_bwd");
     if (coef->pairwise) {
-        if (coef->global_batch != dims->batch) return IVAE_E_BADDIMS;   // DP callers run the phases themselves
-        Layout L;
-        ivae_make_layout(dims, &L);
         for (int m = 0; m < L.n_models; ++m) {
             float* w = (float*)workspace + (size_t)m * L.ws.per_model;
             rc = ivae_pairwise(L.B, L.B, L.dl, coef, w + L.ws.z, w + L.ws.g, w + L.ws.v, w + L.ws.lq, w + L.ws.lqi,
@@ -119,7 +124,8 @@ int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* p
             if (rc) return rc;
         }
     }
-    return ivae_backward(dims, coef, params, x, u, eps, loss_out, grads, workspace, workspace_bytes, stream);
+    e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, true, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_elbo_fwd_bwd");
 }
 
 int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float* grads, int64_t n, double lr,

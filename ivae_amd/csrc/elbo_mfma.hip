@@ -315,39 +315,34 @@ __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const 
     }
 }
 
+// Encoder / prior forward.  blockIdx.z picks the MLP: 0 = g, 1 = logv, 2 = logl; the three chains of a row tile
+// run as three concurrent workgroups (a third of the dependent-layer latency, three times the workgroups).
+// Writes g, v = exp(logv), l = exp(logl) rows to the workspace.
 template <int RTE>
-__global__ __launch_bounds__(NT) void k_forward(Layout L, IvaeCoef C, const float* __restrict__ params,
-                                                const float* __restrict__ x, const float* __restrict__ u,
-                                                const float* __restrict__ eps, float* __restrict__ z_out,
-                                                float* __restrict__ ws) {
+__global__ __launch_bounds__(NT) void k_fwd_enc(Layout L, const float* __restrict__ params, const float* __restrict__ x,
+                                                const float* __restrict__ u, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TR = L.tr, lds = L.lds;
+    const int TR = L.tr;
     float* wbuf = smem;
     float* xin = wbuf + 2 * CHUNK;          // [x | pad | u | 1 | 0..]
     float* h0 = xin + TR * L.ldx;
     float* h1 = h0 + TR * L.ldh;
-    float* sg = h1 + TR * L.ldh;
-    float* sv = sg + TR * lds;
-    float* sl = sv + TR * lds;
-    float* sz = sl + TR * lds;              // z with its constant-1 column
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
-    const int model = blockIdx.y;
-    const int row0 = blockIdx.x * TR;
-    const int nrows = min(TR, L.B - row0);
+    const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
+    const int m = blockIdx.z == 0 ? IVAE_MLP_G : blockIdx.z == 1 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL;
     const float* P = params + (size_t)model * L.n_params;
     float* wsm = ws + (size_t)model * L.ws.per_model;
     const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
     const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
-    const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
     const int Kx = L.uoff + L.M;            // contraction extent of the encoder's first layer (bias column index)
+    const bool enc = m != IVAE_MLP_LOGL;
 
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 0;
     MSTAMP(100);
-    const BSrc first = src_w(L, L.mlp[IVAE_MLP_G], P, 0, L.M > 0);
-    chunk_load(St.r, first, 0, 0);
+    chunk_load(St.r, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), 0, 0);
 
-    for (int i = tid; i < L.smem_fwd / 4 - 2 * CHUNK; i += NT) xin[i] = 0.f;
+    for (int i = tid; i < L.smem_enc / 4 - 2 * CHUNK; i += NT) xin[i] = 0.f;
     __syncthreads();
     for (int idx = tid; idx < TR * (L.dd + L.M); idx += NT) {
         const int r = idx / (L.dd + L.M), k = idx - r * (L.dd + L.M);
@@ -359,86 +354,22 @@ __global__ __launch_bounds__(NT) void k_forward(Layout L, IvaeCoef C, const floa
     for (int r = tid; r < TR; r += NT) {
         xin[r * L.ldx + Kx] = 1.f;
         if (L.L > 1) { h0[r * L.ldh + L.H] = 1.f; h1[r * L.ldh + L.H] = 1.f; }
-        sz[r * lds + L.dl] = 1.f;
     }
     // (the first tile_gemm's barrier orders these writes before any operand read)
-
     FwdCtx X;
     X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.RT = TR >> 4; X.h0 = h0; X.h1 = h1;
-    const bool has_u = L.M > 0;
-    float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
-    // one loop over the MLPs (a single inlined copy of the layer pipeline): g, logv, [logl], then f after the
-    // reparameterisation
-    for (int mi = 0; mi < 4; ++mi) {
-        const int m = mi == 0 ? IVAE_MLP_G : mi == 1 ? IVAE_MLP_LOGV : mi == 2 ? IVAE_MLP_LOGL : IVAE_MLP_F;
-        if (m == IVAE_MLP_LOGL && !has_u) {
-            for (int idx = tid; idx < TR * L.dl; idx += NT) sl[(idx / L.dl) * lds + idx % L.dl] = 1.f;
-            continue;
-        }
-        if (m == IVAE_MLP_F) {
-            __syncthreads();
-            // reparameterisation z = eps*sqrt(v) + g      (models/nets.py:301-304, 145-149)
-            for (int idx = tid; idx < TR * L.dl; idx += NT) {
-                const int r = idx / L.dl, k = idx - r * L.dl;
-                float zz = 0.f;
-                if (r < nrows) {
-                    const float e = em[(size_t)r * L.dl + k];
-                    const float vv = sv[r * lds + k], gg = sg[r * lds + k];
-                    zz = e * sqrtf(vv) + gg;
-                    const size_t o = (size_t)(row0 + r) * L.dl + k;
-                    z_out[(size_t)model * L.B * L.dl + o] = zz;
-                    wsm[L.ws.z + o] = zz;
-                    wsm[L.ws.g + o] = gg;
-                    wsm[L.ws.v + o] = vv;
-                    wsm[L.ws.l + o] = sl[r * lds + k];
-                }
-                sz[r * lds + k] = zz;
-            }
-        }
-        int mn = mi == 0 ? IVAE_MLP_LOGV : mi == 1 ? IVAE_MLP_LOGL : mi == 2 ? IVAE_MLP_F : -1;                // MLP whose first chunk is prefetched at the end
-        if (mn == IVAE_MLP_LOGL && !has_u) mn = IVAE_MLP_F;
-        BSrc next = src_none();
-        if (mn >= 0) next = src_w(L, L.mlp[mn], P, 0, has_u && mn == IVAE_MLP_LOGV);
-        const bool enc = m == IVAE_MLP_G || m == IVAE_MLP_LOGV;
-        const float* in = enc ? xin : m == IVAE_MLP_LOGL ? xin + L.uoff : sz;
-        const int ld_in = m == IVAE_MLP_F ? lds : L.ldx;
-        const int Kin0 = enc ? Kx : m == IVAE_MLP_LOGL ? L.M : L.dl;
-        float* hd = m == IVAE_MLP_G ? sg : m == IVAE_MLP_LOGV ? sv : sl;
-        const int n_out = m == IVAE_MLP_F ? L.dd : L.dl;
-        mlp_fwd<RTE>(L, X, L.mlp[m], in, ld_in, Kin0, enc && has_u, next, St, [&](int rt, int col0, const f32x4& acc) {
-            const int n = col0 + c;
-            if (n < n_out) {
+    float* out = wsm + (m == IVAE_MLP_G ? L.ws.g : m == IVAE_MLP_LOGV ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
+    mlp_fwd<RTE>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
+                 [&](int rt, int col0, const f32x4& acc) {
+                     const int n = col0 + c;
+                     if (n < L.dl) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * rt + 4 * q + r;
-                    if (m == IVAE_MLP_F) { if (row < nrows) fm[(size_t)row * L.dd + n] = acc[r]; }   // decoder output -> workspace
-                    else hd[row * lds + n] = m == IVAE_MLP_G ? acc[r] : expf(acc[r]);
-                }
-            }
-        });
-    }
-    MSTAMP(101);
-    __syncthreads();
-    // per-row Gaussian log-densities   (models/nets.py:306-314, 45-52)
-    if (tid < nrows) {
-        const int r = tid;
-        const float dv = C.decoder_var;
-        const float logdv = logf(dv);
-        float lpx = 0.f, lqc = 0.f, lp = 0.f;
-        for (int k = 0; k < L.dd; ++k) {
-            const float df = xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k];
-            lpx += -0.5f * (LOG2PI + logdv + df * df / dv);
-        }
-        for (int k = 0; k < L.dl; ++k) {
-            const float zz = sz[r * lds + k], gg = sg[r * lds + k], vv = sv[r * lds + k], ll = sl[r * lds + k];
-            const float dq = zz - gg;
-            lqc += -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
-            lp += -0.5f * (LOG2PI + logf(ll) + zz * zz / ll);
-        }
-        wsm[L.ws.lpx + row0 + r] = lpx;
-        wsm[L.ws.lqc + row0 + r] = lqc;
-        wsm[L.ws.lp + row0 + r] = lp;
-    }
+                         for (int r = 0; r < 4; ++r) {
+                             const int row = 16 * rt + 4 * q + r;
+                             if (row < nrows) out[(size_t)row * L.dl + n] = m == IVAE_MLP_G ? acc[r] : expf(acc[r]);
+                         }
+                     }
+                 });
     MSTAMP(102);
 }
 
@@ -542,109 +473,177 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
     }
 }
 
-// head delta (LDS small tile, stride lds) -> delta tile (row-major) and its transpose
-__device__ __forceinline__ void put_delta(const Layout& L, const BwdCtx& X, const float* src, int lds, int n_out) {
-    __syncthreads();       // every wave is done with the previous contents of d[0] / dT
-    for (int idx = threadIdx.x; idx < X.TR * n_out; idx += NT) {
-        const int r = idx / n_out, k = idx - r * n_out;
-        const float v = src[r * lds + k];
-        X.d0[r * L.ldd + k] = v;
-        X.dT[k * L.ldr + r] = v;
+// Decoder kernel.  mode bit 0: reparameterisation, decoder forward, the three per-row log-densities; bit 1: decoder
+// backward (weight-gradient slab of f, dLoss/dz through the decoder -> workspace).  The decoder's backward needs
+// nothing from other rows, so ivae_elbo_fwd_bwd runs both bits in one launch; the encoder / prior head deltas,
+// which take the pairwise terms, are formed later by k_bwd_enc.
+template <int RTE>
+__global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
+                                            const float* __restrict__ x, const float* __restrict__ eps,
+                                            float* __restrict__ z_out, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TR = L.tr, lds = L.lds;
+    const int ldt = max(L.ldh, L.ldd);
+    float* wbuf = smem;
+    float* t0 = wbuf + 2 * CHUNK;           // hidden tiles (forward) / delta tiles (backward)
+    float* t1 = t0 + TR * ldt;
+    float* dT = t1 + TR * ldt;
+    float* sz = dT + L.nT * L.ldr;          // z with its constant-1 column
+    float* sdz = sz + TR * lds;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
+    const float* P = params + (size_t)model * L.n_params;
+    float* wsm = ws + (size_t)model * L.ws.per_model;
+    const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
+    const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
+    float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
+    const float* zrows = wsm + L.ws.z + (size_t)row0 * L.dl;
+    const MlpDesc& DF = L.mlp[IVAE_MLP_F];
+
+    BwdCtx B;
+    B.P = P; B.wsm = wsm; B.slab = wsm + L.ws_partial + (size_t)blockIdx.x * L.n_params;
+    B.row0 = row0; B.nrows = nrows; B.TR = TR; B.d0 = t0; B.d1 = t1; B.dT = dT;
+    const BSrc bwd_first = bwd_src(L, B, DF, 0, zrows, L.dl, nullptr, 0);
+
+    Stream St;
+    St.wbuf = wbuf; St.par = 0; St.n = 0;
+    chunk_load(St.r, (mode & 1) ? src_w(L, DF, P, 0, false) : bwd_first, 0, 0);
+    for (int i = tid; i < L.smem_dec / 4 - 2 * CHUNK; i += NT) t0[i] = 0.f;
+    __syncthreads();
+
+    if (mode & 1) {
+        for (int r = tid; r < TR; r += NT) {
+            if (L.L > 1) { t0[r * L.ldh + L.H] = 1.f; t1[r * L.ldh + L.H] = 1.f; }
+            sz[r * lds + L.dl] = 1.f;
+        }
+        // reparameterisation z = eps*sqrt(v) + g      (models/nets.py:301-304, 145-149)
+        for (int idx = tid; idx < TR * L.dl; idx += NT) {
+            const int r = idx / L.dl, k = idx - r * L.dl;
+            float zz = 0.f;
+            if (r < nrows) {
+                const size_t o = (size_t)(row0 + r) * L.dl + k;
+                zz = em[(size_t)r * L.dl + k] * sqrtf(wsm[L.ws.v + o]) + wsm[L.ws.g + o];
+                z_out[(size_t)model * L.B * L.dl + o] = zz;
+                wsm[L.ws.z + o] = zz;
+                if (L.M == 0) wsm[L.ws.l + o] = 1.f;
+            }
+            sz[r * lds + k] = zz;
+        }
+        FwdCtx X;
+        X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.RT = TR >> 4; X.h0 = t0; X.h1 = t1;
+        mlp_fwd<RTE>(L, X, DF, sz, lds, L.dl, false, (mode & 2) ? bwd_first : src_none(), St,
+                     [&](int rt, int col0, const f32x4& acc) {
+                         const int n = col0 + c;
+                         if (n < L.dd) {
+#pragma unroll
+                             for (int r = 0; r < 4; ++r) {
+                                 const int row = 16 * rt + 4 * q + r;
+                                 if (row < nrows) fm[(size_t)row * L.dd + n] = acc[r];
+                             }
+                         }
+                     });
+        __syncthreads();
+        // per-row Gaussian log-densities   (models/nets.py:306-314, 45-52)
+        if (tid < nrows) {
+            const int r = tid;
+            const float dv = C.decoder_var;
+            const float logdv = logf(dv);
+            float lpx = 0.f, lqc = 0.f, lp = 0.f;
+            for (int k = 0; k < L.dd; ++k) {
+                const float df = xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k];
+                lpx += -0.5f * (LOG2PI + logdv + df * df / dv);
+            }
+            for (int k = 0; k < L.dl; ++k) {
+                const size_t o = (size_t)(row0 + r) * L.dl + k;
+                const float zz = sz[r * lds + k], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o];
+                const float ll = L.M > 0 ? wsm[L.ws.l + o] : 1.f;
+                const float dq = zz - gg;
+                lqc += -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
+                lp += -0.5f * (LOG2PI + logf(ll) + zz * zz / ll);
+            }
+            wsm[L.ws.lpx + row0 + r] = lpx;
+            wsm[L.ws.lqc + row0 + r] = lqc;
+            wsm[L.ws.lp + row0 + r] = lp;
+        }
+    }
+    if (mode & 2) {
+        // dLoss/df = -a*w*(x-f)/var, all TR rows (zero beyond the batch): the tiles may hold forward activations
+        const float w = 1.f / (float)C.global_batch;
+        __syncthreads();
+        for (int idx = tid; idx < TR * L.dd; idx += NT) {
+            const int r = idx / L.dd, k = idx - r * L.dd;
+            const float v = r < nrows ? -C.a * w * (xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k]) / C.decoder_var : 0.f;
+            t0[r * L.ldd + k] = v;
+            dT[k * L.ldr + r] = v;
+        }
+        mlp_bwd<RTE>(L, B, DF, zrows, L.dl, nullptr, 0, sdz, lds, src_none(), St);
+        __syncthreads();
+        for (int idx = tid; idx < nrows * L.dl; idx += NT) {
+            const int r = idx / L.dl, k = idx - r * L.dl;
+            wsm[L.ws_dz + (size_t)(row0 + r) * L.dl + k] = sdz[r * lds + k];
+        }
     }
 }
 
+// Encoder / prior backward.  blockIdx.z picks the MLP: 0 = g, 1 = logv, 2 = logl (three concurrent workgroups per row
+// tile).  Forms the output-layer delta of its head (SURVEY.md §8 a-bwd; pairwise terms included) and runs the chain.
 template <int RTE>
-__global__ __launch_bounds__(NT) void k_backward(Layout L, IvaeCoef C, const float* __restrict__ params,
-                                                 const float* __restrict__ x, const float* __restrict__ u,
-                                                 const float* __restrict__ eps, float* __restrict__ ws) {
+__global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const float* __restrict__ params,
+                                                const float* __restrict__ x, const float* __restrict__ u,
+                                                const float* __restrict__ eps, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int TR = L.tr, lds = L.lds;
+    const int TR = L.tr;
     float* wbuf = smem;
     float* dA = wbuf + 2 * CHUNK;
     float* dB = dA + TR * L.ldd;
     float* dT = dB + TR * L.ldd;
-    float* sdz = dT + L.nT * L.ldr;      // dLoss/dz through the decoder
-    float* sdg = sdz + TR * lds;
-    float* sdv = sdg + TR * lds;
-    float* sdl = sdv + TR * lds;
     const int tid = threadIdx.x;
-    const int model = blockIdx.y;
-    const int row0 = blockIdx.x * TR;
-    const int nrows = min(TR, L.B - row0);
+    const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
+    const int mi = blockIdx.z;
+    const int m = mi == 0 ? IVAE_MLP_G : mi == 1 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL;
     const float* P = params + (size_t)model * L.n_params;
     float* wsm = ws + (size_t)model * L.ws.per_model;
     const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
     const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
     const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
     const float w = 1.f / (float)C.global_batch;
+    const bool pri = m == IVAE_MLP_LOGL;
 
     BwdCtx X;
     X.P = P; X.wsm = wsm; X.slab = wsm + L.ws_partial + (size_t)blockIdx.x * L.n_params;
     X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = dA; X.d1 = dB; X.dT = dT;
-    const float* zrows = wsm + L.ws.z + (size_t)row0 * L.dl;
-    const MlpDesc& DF = L.mlp[IVAE_MLP_F];
+    const float* in_a = pri ? um : xm;
+    const int na = pri ? L.M : L.dd;
+    const float* in_b = pri ? nullptr : um;
+    const int nb = pri ? 0 : L.M;
 
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 0;
-    chunk_load(St.r, bwd_src(L, X, DF, 0, zrows, L.dl, nullptr, 0), 0, 0);
-
-    for (int i = tid; i < L.smem_bwd / 4 - 2 * CHUNK; i += NT) dA[i] = 0.f;
+    chunk_load(St.r, bwd_src(L, X, L.mlp[m], 0, in_a, na, in_b, nb), 0, 0);
+    for (int i = tid; i < L.smem_benc / 4 - 2 * CHUNK; i += NT) dA[i] = 0.f;
     __syncthreads();
-    // dLoss/df = -a*w*(x-f)/var
-    const float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
-    for (int idx = tid; idx < nrows * L.dd; idx += NT) {
-        const int r = idx / L.dd, k = idx - r * L.dd;
-        const float v = -C.a * w * (xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k]) / C.decoder_var;
-        dA[r * L.ldd + k] = v;
-        dT[k * L.ldr + r] = v;
-    }
-    // one loop over the MLPs (a single inlined copy of the layer pipeline): f, then g, logv, [logl]
-    const int n_mlp = L.M > 0 ? 4 : 3;
-    for (int mi = 0; mi < n_mlp; ++mi) {
-        const bool dec = mi == 0, pri = mi == 3;
-        const MlpDesc& D = L.mlp[dec ? IVAE_MLP_F : mi == 1 ? IVAE_MLP_G : mi == 2 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL];
-        const float* in_a = dec ? zrows : pri ? um : xm;
-        const int na = dec ? L.dl : pri ? L.M : L.dd;
-        const float* in_b = (dec || pri) ? nullptr : um;
-        const int nb = (dec || pri) ? 0 : L.M;
-        BSrc next = src_none();
-        if (mi + 1 < n_mlp) {
-            const bool npri = mi + 1 == 3;
-            next = bwd_src(L, X, L.mlp[mi + 1 == 1 ? IVAE_MLP_G : mi + 1 == 2 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL], 0, npri ? um : xm, npri ? L.M : L.dd,
-                           npri ? nullptr : um, npri ? 0 : L.M);
+    for (int idx = tid; idx < nrows * L.dl; idx += NT) {
+        const int r = idx / L.dl, k = idx - r * L.dl;
+        const size_t o = (size_t)(row0 + r) * L.dl + k;
+        const float zz = wsm[L.ws.z + o], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o], ll = wsm[L.ws.l + o];
+        const float dq = zz - gg;
+        const float rr = dq / vv;
+        float Gz = wsm[L.ws_dz + o] - w * (C.b * rr - C.d * zz / ll);
+        if (C.pairwise) Gz -= w * wsm[L.ws.rz + o];
+        float dlt;
+        if (mi == 0) {
+            dlt = w * C.b * rr + Gz;
+            if (C.pairwise) dlt -= w * wsm[L.ws.cg + o];
+        } else if (mi == 1) {
+            dlt = -w * C.b * 0.5f * (1.f - dq * dq / vv) + Gz * 0.5f * em[(size_t)r * L.dl + k] * sqrtf(vv);
+            if (C.pairwise) dlt -= w * wsm[L.ws.cv + o];
+        } else {
+            dlt = w * C.d * 0.5f * (1.f - zz * zz / ll);
         }
-        if (!dec) put_delta(L, X, mi == 1 ? sdg : mi == 2 ? sdv : sdl, lds, L.dl);
-        mlp_bwd<RTE>(L, X, D, in_a, na, in_b, nb, dec ? sdz : nullptr, lds, next, St);
-        if (dec) {
-            __syncthreads();
-            // output-layer deltas of the encoder / prior heads (SURVEY.md §8 a-bwd)
-            for (int idx = tid; idx < TR * L.dl; idx += NT) {
-                const int r = idx / L.dl, k = idx - r * L.dl;
-                float dg = 0.f, dv = 0.f, dlg = 0.f;
-                if (r < nrows) {
-                    const size_t o = (size_t)(row0 + r) * L.dl + k;
-                    const float zz = wsm[L.ws.z + o], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o], ll = wsm[L.ws.l + o];
-                    const float e = em[(size_t)r * L.dl + k];
-                    const float dq = zz - gg;
-                    const float rr = dq / vv;
-                    float Gz = sdz[r * lds + k] - w * (C.b * rr - C.d * zz / ll);
-                    dg = w * C.b * rr;
-                    dv = -w * C.b * 0.5f * (1.f - dq * dq / vv);
-                    if (C.pairwise) {
-                        Gz -= w * wsm[L.ws.rz + o];
-                        dg -= w * wsm[L.ws.cg + o];
-                        dv -= w * wsm[L.ws.cv + o];
-                    }
-                    dg += Gz;
-                    dv += Gz * 0.5f * e * sqrtf(vv);
-                    dlg = w * C.d * 0.5f * (1.f - zz * zz / ll);
-                }
-                sdg[r * lds + k] = dg;
-                sdv[r * lds + k] = dv;
-                sdl[r * lds + k] = dlg;
-            }
-        }
+        dA[r * L.ldd + k] = dlt;
+        dT[k * L.ldr + r] = dlt;
     }
+    mlp_bwd<RTE>(L, X, L.mlp[m], in_a, na, in_b, nb, nullptr, 0, src_none(), St);
 }
 
 // Sum the per-tile slabs into grads and reduce the loss.  A block sums 64 parameters: wave g adds the tiles
@@ -708,40 +707,45 @@ static hipError_t set_smem(const void* fn, int bytes, int& cur) {
 }
 
 template <int RTE>
-static hipError_t launch_forward_t(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                                   const float* eps, float* z_out, float* ws, hipStream_t st) {
-    static int cur = 64 * 1024;
-    hipError_t e = set_smem((const void*)k_forward<RTE>, L.smem_fwd, cur);
-    if (e != hipSuccess) return e;
-    dim3 grid(L.n_tiles, L.n_models);
-    hipLaunchKernelGGL(k_forward<RTE>, grid, dim3(NT), L.smem_fwd, st, L, C, params, x, u, eps, z_out, ws);
+static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
+                           const float* eps, float* z_out, float* ws, hipStream_t st) {
+    static int cur_enc = 64 * 1024, cur_dec = 64 * 1024, cur_benc = 64 * 1024;
+    const int nz = L.M > 0 ? 3 : 2;
+    hipError_t e;
+    if (what == 0) {            // encoder / prior forward
+        if ((e = set_smem((const void*)k_fwd_enc<RTE>, L.smem_enc, cur_enc)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fwd_enc<RTE>, dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_enc, st, L, params, x, u, ws);
+    } else if (what <= 3) {     // decoder: mode = what
+        if ((e = set_smem((const void*)k_dec<RTE>, L.smem_dec, cur_dec)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_dec<RTE>, dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws);
+    } else {                    // encoder / prior backward
+        if ((e = set_smem((const void*)k_bwd_enc<RTE>, L.smem_benc, cur_benc)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_bwd_enc<RTE>, dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws);
+    }
     return hipGetLastError();
 }
 
+static hipError_t launch_phase(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
+                               const float* eps, float* z_out, float* ws, hipStream_t st) {
+    if (L.tr == 16) return launch_t<1>(L, C, what, params, x, u, eps, z_out, ws, st);
+    if (L.tr == 32) return launch_t<2>(L, C, what, params, x, u, eps, z_out, ws, st);
+    return launch_t<4>(L, C, what, params, x, u, eps, z_out, ws, st);
+}
+
+// with_dec_bwd: also run the decoder's backward inside the decoder launch (the caller then passes
+// dec_bwd_done = true to launch_backward).
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                          const float* eps, float* z_out, float* ws, hipStream_t st) {
-    if (L.tr == 16) return launch_forward_t<1>(L, C, params, x, u, eps, z_out, ws, st);
-    if (L.tr == 32) return launch_forward_t<2>(L, C, params, x, u, eps, z_out, ws, st);
-    return launch_forward_t<4>(L, C, params, x, u, eps, z_out, ws, st);
-}
-
-template <int RTE>
-static hipError_t launch_backward_t(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                                    const float* eps, float* ws, hipStream_t st) {
-    static int cur = 64 * 1024;
-    hipError_t e = set_smem((const void*)k_backward<RTE>, L.smem_bwd, cur);
+                          const float* eps, float* z_out, float* ws, bool with_dec_bwd, hipStream_t st) {
+    hipError_t e = launch_phase(L, C, 0, params, x, u, eps, z_out, ws, st);
     if (e != hipSuccess) return e;
-    dim3 grid(L.n_tiles, L.n_models);
-    hipLaunchKernelGGL(k_backward<RTE>, grid, dim3(NT), L.smem_bwd, st, L, C, params, x, u, eps, ws);
-    return hipGetLastError();
+    return launch_phase(L, C, with_dec_bwd ? 3 : 1, params, x, u, eps, z_out, ws, st);
 }
 
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                           const float* eps, float* loss_out, float* grads, float* ws, hipStream_t st) {
-    hipError_t e = L.tr == 16 ? launch_backward_t<1>(L, C, params, x, u, eps, ws, st)
-                 : L.tr == 32 ? launch_backward_t<2>(L, C, params, x, u, eps, ws, st)
-                              : launch_backward_t<4>(L, C, params, x, u, eps, ws, st);
-    if (e != hipSuccess) return e;
+                           const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st) {
+    hipError_t e;
+    if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, st)) != hipSuccess) return e;
+    if ((e = launch_phase(L, C, 4, params, x, u, eps, nullptr, ws, st)) != hipSuccess) return e;
     dim3 g2((L.n_params + RED_P - 1) / RED_P + 1, L.n_models);
     hipLaunchKernelGGL(k_reduce, g2, dim3(NT), 0, st, L, C, ws, grads, loss_out);
     return hipGetLastError();

@@ -4,9 +4,9 @@
 #include "layout.h"
 
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                          const float* eps, float* z_out, float* ws, hipStream_t st);
+                          const float* eps, float* z_out, float* ws, bool with_dec_bwd, hipStream_t st);
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                           const float* eps, float* loss_out, float* grads, float* ws, hipStream_t st);
+                           const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st);
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
                            const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
                            float* cg, float* cv, float* ws, hipStream_t st);

@@ -40,7 +40,8 @@ struct Layout {
     int uoff;            // column of u inside the [x | pad | u | 1] input tile (multiple of 4)
     int ldx, ldh, lds;   // LDS row strides (4 * odd floats): input tile, hidden tiles, latent-width tiles
     int ldd, ldr, nT;    // delta tiles (row-major stride), transposed delta (stride, rows)
-    int smem_fwd, smem_bwd;   // dynamic LDS bytes
+    int smem_enc, smem_dec, smem_benc;   // dynamic LDS bytes of k_fwd_enc, k_dec, k_bwd_enc
+    int64_t ws_dz;       // (B, dl) dLoss/dz through the decoder (k_dec -> k_bwd_enc)
 };
 
 #define IVAE_CHUNK_FLOATS (64 * 68)      // one streamed operand chunk (elbo_mfma.hip)
@@ -49,6 +50,7 @@ struct Layout {
 static inline int ivae_up16(int x) { return (x + 15) & ~15; }
 static inline int ivae_ld4o(int x) { return (((x + 3) >> 2) | 1) << 2; }     // smallest 4*odd >= x
 
+static inline bool ivae_lds_over(const Layout& L);
 static inline void ivae_tile_geometry(Layout& L, int tr) {
     const int wide = L.maxh;
     L.tr = tr;
@@ -59,8 +61,14 @@ static inline void ivae_tile_geometry(Layout& L, int tr) {
     L.nT = ivae_up16(wide);
     L.ldr = tr + 4;
     // +64 floats: k-steps past a tile's last column read (finite) neighbours; the last tile needs room for that
-    L.smem_fwd = 4 * (2 * IVAE_CHUNK_FLOATS + tr * L.ldx + 2 * tr * L.ldh + 4 * tr * L.lds + 64);
-    L.smem_bwd = 4 * (2 * IVAE_CHUNK_FLOATS + 2 * tr * L.ldd + L.nT * L.ldr + 4 * tr * L.lds + 64);
+    const int ldt = L.ldh > L.ldd ? L.ldh : L.ldd;
+    L.smem_enc = 4 * (2 * IVAE_CHUNK_FLOATS + tr * L.ldx + 2 * tr * L.ldh + 64);
+    L.smem_dec = 4 * (2 * IVAE_CHUNK_FLOATS + 2 * tr * ldt + L.nT * L.ldr + 2 * tr * L.lds + 64);
+    L.smem_benc = 4 * (2 * IVAE_CHUNK_FLOATS + 2 * tr * L.ldd + L.nT * L.ldr + 64);
+}
+
+static inline bool ivae_lds_over(const Layout& L) {
+    return L.smem_enc > IVAE_LDS_LIMIT || L.smem_dec > IVAE_LDS_LIMIT || L.smem_benc > IVAE_LDS_LIMIT;
 }
 
 static inline int ivae_check_dims(const IvaeDims* d) {
@@ -120,10 +128,11 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
         if (v == 16 || v == 32 || v == 64) tr = v;
     }
     ivae_tile_geometry(L, tr);
-    while (tr > 16 && (L.smem_fwd > IVAE_LDS_LIMIT || L.smem_bwd > IVAE_LDS_LIMIT)) { tr >>= 1; ivae_tile_geometry(L, tr); }
-    if (L.smem_fwd > IVAE_LDS_LIMIT || L.smem_bwd > IVAE_LDS_LIMIT) return IVAE_E_TOOLARGE;
+    while (tr > 16 && ivae_lds_over(L)) { tr >>= 1; ivae_tile_geometry(L, tr); }
+    if (ivae_lds_over(L)) return IVAE_E_TOOLARGE;
     L.n_tiles = (L.B + tr - 1) / tr;
     L.ws_partial = take((int64_t)L.n_tiles * L.n_params);
+    L.ws_dz = take(Bl);
     L.ws_pair = take((int64_t)ivae_pair_ws_floats(L.B, L.B, L.dl));
     wso = (wso + 63) & ~(int64_t)63;
     L.ws.per_model = wso;
