@@ -62,7 +62,7 @@ int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params
     if ((rc = check_coef(dims, coef))) return rc;
     if (!params || !x || !eps || !z_out || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
     if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
-    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, false, (hipStream_t)stream);
+    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, nullptr, (hipStream_t)stream);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_forward");
 }
 
@@ -113,7 +113,7 @@ int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* p
     if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
     if (coef->pairwise && coef->global_batch != dims->batch) return IVAE_E_BADDIMS;   // DP callers run the phases themselves
     // the decoder's backward rides in the decoder's forward launch (it needs nothing from other rows)
-    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, true, (hipStream_t)stream);
+    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, grads, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "ivae_elbo_fwd_bwd");
     if (coef->pairwise) {
         for (int m = 0; m < L.n_models; ++m) {

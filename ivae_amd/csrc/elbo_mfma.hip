@@ -480,7 +480,8 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
 template <int RTE>
 __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
                                             const float* __restrict__ x, const float* __restrict__ eps,
-                                            float* __restrict__ z_out, float* __restrict__ ws) {
+                                            float* __restrict__ z_out, float* __restrict__ ws, float* __restrict__ slabs,
+                                            long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TR = L.tr, lds = L.lds;
     const int ldt = max(L.ldh, L.ldd);
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
     const MlpDesc& DF = L.mlp[IVAE_MLP_F];
 
     BwdCtx B;
-    B.P = P; B.wsm = wsm; B.slab = wsm + L.ws_partial + (size_t)blockIdx.x * L.n_params;
+    B.P = P; B.wsm = wsm; B.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.n_params;
     B.row0 = row0; B.nrows = nrows; B.TR = TR; B.d0 = t0; B.d1 = t1; B.dT = dT;
     const BSrc bwd_first = bwd_src(L, B, DF, 0, zrows, L.dl, nullptr, 0);
 
@@ -590,7 +591,8 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
 template <int RTE>
 __global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const float* __restrict__ params,
                                                 const float* __restrict__ x, const float* __restrict__ u,
-                                                const float* __restrict__ eps, float* __restrict__ ws) {
+                                                const float* __restrict__ eps, float* __restrict__ ws,
+                                                float* __restrict__ slabs, long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TR = L.tr;
     float* wbuf = smem;
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const floa
     const bool pri = m == IVAE_MLP_LOGL;
 
     BwdCtx X;
-    X.P = P; X.wsm = wsm; X.slab = wsm + L.ws_partial + (size_t)blockIdx.x * L.n_params;
+    X.P = P; X.wsm = wsm; X.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.n_params;
     X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = dA; X.d1 = dB; X.dT = dT;
     const float* in_a = pri ? um : xm;
     const int na = pri ? L.M : L.dd;
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(NT) void k_reduce(Layout L, IvaeCoef C, const float
                                                float* __restrict__ grads, float* __restrict__ loss_out) {
     const int model = blockIdx.y;
     const float* wsm = ws + (size_t)model * L.ws.per_model;
-    const int nblk_p = (L.n_params + RED_P - 1) / RED_P;
+    const int nblk_p = L.n_tiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;   // one tile: the kernels wrote grads directly
     __shared__ float red[NT];
     if ((int)blockIdx.x < nblk_p) {
         const int p = min((int)blockIdx.x * RED_P + (int)(threadIdx.x & 63), L.n_params - 1);
@@ -708,45 +710,51 @@ static hipError_t set_smem(const void* fn, int bytes, int& cur) {
 
 template <int RTE>
 static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
-                           const float* eps, float* z_out, float* ws, hipStream_t st) {
+                           const float* eps, float* z_out, float* ws, float* grads, hipStream_t st) {
     static int cur_enc = 64 * 1024, cur_dec = 64 * 1024, cur_benc = 64 * 1024;
     const int nz = L.M > 0 ? 3 : 2;
+    // gradient slabs: per-tile partials in the workspace, or the caller's gradient buffer itself when a model is one tile
+    float* slabs = L.n_tiles > 1 ? ws + L.ws_partial : grads;
+    const long slab_stride = L.n_tiles > 1 ? (long)L.ws.per_model : (long)L.n_params;
     hipError_t e;
     if (what == 0) {            // encoder / prior forward
         if ((e = set_smem((const void*)k_fwd_enc<RTE>, L.smem_enc, cur_enc)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_fwd_enc<RTE>, dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_enc, st, L, params, x, u, ws);
     } else if (what <= 3) {     // decoder: mode = what
         if ((e = set_smem((const void*)k_dec<RTE>, L.smem_dec, cur_dec)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_dec<RTE>, dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws);
+        hipLaunchKernelGGL(k_dec<RTE>, dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws,
+                           slabs, slab_stride);
     } else {                    // encoder / prior backward
         if ((e = set_smem((const void*)k_bwd_enc<RTE>, L.smem_benc, cur_benc)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_bwd_enc<RTE>, dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws);
+        hipLaunchKernelGGL(k_bwd_enc<RTE>, dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws,
+                           slabs, slab_stride);
     }
     return hipGetLastError();
 }
 
 static hipError_t launch_phase(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
-                               const float* eps, float* z_out, float* ws, hipStream_t st) {
-    if (L.tr == 16) return launch_t<1>(L, C, what, params, x, u, eps, z_out, ws, st);
-    if (L.tr == 32) return launch_t<2>(L, C, what, params, x, u, eps, z_out, ws, st);
-    return launch_t<4>(L, C, what, params, x, u, eps, z_out, ws, st);
+                               const float* eps, float* z_out, float* ws, float* grads, hipStream_t st) {
+    if (L.tr == 16) return launch_t<1>(L, C, what, params, x, u, eps, z_out, ws, grads, st);
+    if (L.tr == 32) return launch_t<2>(L, C, what, params, x, u, eps, z_out, ws, grads, st);
+    return launch_t<4>(L, C, what, params, x, u, eps, z_out, ws, grads, st);
 }
 
-// with_dec_bwd: also run the decoder's backward inside the decoder launch (the caller then passes
+// grads_for_dec_bwd != null: also run the decoder's backward inside the decoder launch (the caller then passes
 // dec_bwd_done = true to launch_backward).
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                          const float* eps, float* z_out, float* ws, bool with_dec_bwd, hipStream_t st) {
-    hipError_t e = launch_phase(L, C, 0, params, x, u, eps, z_out, ws, st);
+                          const float* eps, float* z_out, float* ws, float* grads_for_dec_bwd, hipStream_t st) {
+    hipError_t e = launch_phase(L, C, 0, params, x, u, eps, z_out, ws, nullptr, st);
     if (e != hipSuccess) return e;
-    return launch_phase(L, C, with_dec_bwd ? 3 : 1, params, x, u, eps, z_out, ws, st);
+    return launch_phase(L, C, grads_for_dec_bwd ? 3 : 1, params, x, u, eps, z_out, ws, grads_for_dec_bwd, st);
 }
 
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
                            const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st) {
     hipError_t e;
-    if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, st)) != hipSuccess) return e;
-    if ((e = launch_phase(L, C, 4, params, x, u, eps, nullptr, ws, st)) != hipSuccess) return e;
-    dim3 g2((L.n_params + RED_P - 1) / RED_P + 1, L.n_models);
-    hipLaunchKernelGGL(k_reduce, g2, dim3(NT), 0, st, L, C, ws, grads, loss_out);
+    if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
+    if ((e = launch_phase(L, C, 4, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
+    const int nblk_p = L.n_tiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
+    if (nblk_p == 0 && !loss_out) return hipSuccess;
+    hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(NT), 0, st, L, C, ws, grads, loss_out);
     return hipGetLastError();
 }

@@ -4,7 +4,7 @@
 #include "layout.h"
 
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                          const float* eps, float* z_out, float* ws, bool with_dec_bwd, hipStream_t st);
+                          const float* eps, float* z_out, float* ws, float* grads_for_dec_bwd, hipStream_t st);
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
                            const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st);
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
