@@ -34,7 +34,7 @@ struct Layout {
     IvaeWsLayout ws;
     int64_t ws_partial;  // (n_tiles, n_params) per-tile gradient slabs
     int64_t ws_pair;     // scratch of the pairwise kernels for a (B, B, dl) problem
-    // row tiling of k_forward / k_backward (elbo_mfma.hip)
+    // row tiling of k_fwd_enc / k_dec / k_bwd_enc (elbo_mfma.hip)
     int tr, n_tiles;     // rows per workgroup (16, 32 or 64), workgroups per model
     int Bp;              // batch rounded up to 64: leading dimension of the feature-major pre-activations
     int uoff;            // column of u inside the [x | pad | u | 1] input tile (multiple of 4)

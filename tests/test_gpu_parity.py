@@ -296,7 +296,7 @@ def test_bad_inputs_raise():
 @pytest.mark.parametrize("name", ["ivae_plain_b70", "cleanivae_cfg1", "cleanvae_btcvae_b200", "ivae_plain_cfg4s",
                                   "ivae_plain_l4_none", "ivae_plain_l1"])
 def test_every_row_tiling_matches_reference_fixture(name, tile_rows, monkeypatch):
-    """k_forward / k_backward pick 16, 32 or 64 batch rows per workgroup from the launch geometry (each is its own
+    """The generic kernels pick 16, 32 or 64 batch rows per workgroup from the launch geometry (each is its own
     wave -> tile map); IVAE_AMD_TILE_ROWS pins the choice so that every variant meets the same 1e-5 bar on ragged
     batches, H = 100 xtanh, 1- and 4-layer MLPs."""
     monkeypatch.setenv("IVAE_AMD_TILE_ROWS", str(tile_rows))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase anatomy of k_forward / k_backward from the s_memtime stamps of the -DMF_PROF diagnostic build.
+"""Phase anatomy of k_fwd_enc / k_dec / k_bwd_enc from the s_memtime stamps of the -DMF_PROF diagnostic build.
 usage: IVAE_AMD_LIB=build/libivae_mfprof.so prof_mfma.py cfg"""
 import ctypes as C
 import os
