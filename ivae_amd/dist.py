@@ -127,8 +127,12 @@ class DataParallelELBO:
             self.ws.view('cg', Bl, dl).copy_(cg[lo:hi])
             self.ws.view('cv', Bl, dl).copy_(cv[lo:hi])
             loss, grads = be.backward(sh, coef, params, x, u, eps, self.ws)
-        self._all_reduce(grads)
-        self._all_reduce(loss)
+        if self.world > 1:
+            # ONE collective per step: the loss rides behind the gradient (the exchange is latency-bound, 80-190 KB)
+            flat = torch.cat([grads.reshape(-1), loss.reshape(-1)])
+            self._all_reduce(flat)
+            grads = flat[:grads.numel()].view_as(grads)
+            loss = flat[grads.numel():].view_as(loss)
         return loss, z, grads
 
 
