@@ -38,7 +38,7 @@
 __device__ unsigned long long* g_mf_prof = nullptr;
 #define MSTAMP(id)                                                                                  \
     do {                                                                                            \
-        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_mf_prof && St.n < 2000) {    \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && g_mf_prof && St.n < 2000) {    \
             unsigned long long t_;                                                                  \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
             g_mf_prof[2 * St.n] = (id);                                                             \
@@ -96,50 +96,59 @@ struct BSrc {
     int ld, ld2;
     int hole0, hole;
     int act; float slope;
+    unsigned lim;                   // SRC_W / SRC_PRE: floats readable from p (range of the buffer descriptor)
 };
 
-// One 64 x 64 chunk (j0.., k0..) moves through 16 registers per thread.  LOAD: issue the global loads (unconditional,
-// from always-valid addresses: nothing here waits for memory).  !LOAD: registers -> LDS chunk buffer wb, applying the
-// zero / one fill and the activation.  Element e of thread (w = wave, l = lane):
-//   direct kinds (W, PRE: global memory contiguous along k):  j = w + 4e, k = l
-//   transposing kinds (WT, ROWS: contiguous along j):         j = (l & 7) + 8w + 32(e & 1), k = (l >> 3) + 8(e >> 1)
-//   (8 consecutive j x 8 k per wave keep both the 32-B global segments and the LDS banks of the transposed store distinct)
+// One 64 x 64 chunk (j0.., k0..) moves through 16 (+4) registers per thread.  LOAD: issue the global loads (unconditional:
+// nothing here waits for memory).  !LOAD: registers -> LDS chunk buffer wb, applying the zero / one fill and the
+// activation.  Thread (jq = tid >> 4, kq = tid & 15):
+//   direct kinds (W, PRE: global memory contiguous along k): rows j = jq + 16e, e < 4, columns k = 4kq..4kq+3 as ONE
+//     buffer_load_dwordx4 (dword-aligned; the descriptor's range check returns 0 past the arena, so no clamping) and ONE
+//     ds_write_b128; per-row offsets are scalar (soffset), so a chunk costs one address computation per thread;
+//   transposing kinds (WT, ROWS: contiguous along j), thread (w = tid >> 6, l = tid & 63), 16 scalar elements:
+//     j = (l & 7) + 8w + 32(e & 1), k = (l >> 3) + 8(e >> 1)  (8 consecutive j x 8 k per wave keep both the 32-B global
+//     segments and the LDS banks of the transposed store distinct); out-of-range elements read a clamped address.
 template <bool LOAD>
-__device__ __forceinline__ void chunk_io(float (&r)[16], const BSrc& S, int j0, int k0, float* wb) {
+__device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const BSrc& S, int j0, int k0, float* wb) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));       // opaque: keeps the per-element addresses of every call site from being hoisted
                                         // out of the layer loops (hundreds of live registers otherwise)
     const int w = tid >> 6, l = tid & 63;
+    const int jq = tid >> 4, kq = tid & 15;
     const float* __restrict__ p = S.p;
-    // every element is ONE load; out-of-range elements read a clamped (valid) address and are replaced when the
-    // chunk is stored: min/select only, no control flow; offsets advance by uniform strides from one per-thread base
-    if (S.kind == SRC_W) {
-        int k = k0 + l;
-        const bool in_hole = k >= S.hole0 && k < S.hole0 + S.hole;
-        if (k >= S.hole0 + S.hole) k -= S.hole;
-        const bool in_k = k < S.K && !in_hole, is_b = k == S.K && !in_hole;
-        const int kc = min(k, S.K - 1);
-        // row j = j0 + w + 4e: weight W[j][kc] or bias[j]; rows past the end clamp to the last one
-        const int step = is_b ? 4 : 4 * S.ld;
-        const int base = is_b ? (int)S.d2 + j0 + w : (j0 + w) * S.ld + kc;
-        const int last = is_b ? (int)S.d2 + S.J - 1 : (S.J - 1) * S.ld + kc;
-        const int jlim = S.J - j0 - w;                     // element e is a real row iff 4e < jlim
-        float* dst = wb + w * LDC + l;
+    if (S.kind == SRC_W || S.kind == SRC_PRE) {
+        const bool isw = S.kind == SRC_W;
+        const int kf = k0 + 4 * kq;                                  // contraction index of my first column
+        const int sh = (isw && kf >= S.hole0 + S.hole) ? S.hole : 0;   // (hole0 + hole is a multiple of 4: uniform per group)
+        const int c0 = kf - sh;                                      // its column in memory
+        if (LOAD) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(S.lim * 4u), 0x00020000);
+            const int vo = ((j0 + jq) * S.ld + c0) * 4, vb = ((int)S.d2 + j0 + jq) * 4;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (LOAD) r[e] = p[min(base + e * step, last)];
-            else dst[e * 4 * LDC] = ((in_k || is_b) && 4 * e < jlim) ? r[e] : 0.f;
-        }
-    } else if (S.kind == SRC_PRE) {
-        const int k = k0 + l;
-        const bool in_k = k < S.K;
-        const int base = (j0 + w) * S.ld + k, last = (S.J - 1) * S.ld + k;   // k < 64 <= Bp - row0: inside the padded row
-        const int jlim = S.J - j0 - w;
-        float* dst = wb + w * LDC + l;
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, e * 64 * S.ld, 0));
+                r[4 * e] = t[0]; r[4 * e + 1] = t[1]; r[4 * e + 2] = t[2]; r[4 * e + 3] = t[3];
+                if (isw) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vb, e * 64, 0));
+            }
+        } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (LOAD) r[e] = p[min(base + e * 4 * S.ld, last)];
-            else dst[e * 4 * LDC] = (in_k && 4 * e < jlim) ? act_fwd(r[e], S.act, S.slope) : (in_k && 4 * e == jlim) ? 1.f : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + jq + 16 * e;
+                f32x4 o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = kf + i, cc = c0 + i;
+                    float v;
+                    if (isw) {
+                        const bool ok = j < S.J && !(k >= S.hole0 && k < S.hole0 + S.hole);
+                        v = (ok && cc < S.K) ? r[4 * e + i] : (ok && cc == S.K) ? rb[e] : 0.f;
+                    } else {
+                        v = (k < S.K && j < S.J) ? act_fwd(r[4 * e + i], S.act, S.slope) : (k < S.K && j == S.J) ? 1.f : 0.f;
+                    }
+                    o[i] = v;
+                }
+                *reinterpret_cast<f32x4*>(wb + (jq + 16 * e) * LDC + 4 * kq) = o;
+            }
         }
     } else if (S.kind == SRC_WT) {
         const int jl = (l & 7) + 8 * w, kl = l >> 3;
@@ -173,30 +182,32 @@ __device__ __forceinline__ void chunk_io(float (&r)[16], const BSrc& S, int j0, 
     }
 }
 
-__device__ __forceinline__ void chunk_load(float (&r)[16], const BSrc& S, int j0, int k0) {
-    chunk_io<true>(r, S, j0, k0, nullptr);
-}
-__device__ __forceinline__ void chunk_store(float (&r)[16], const BSrc& S, int j0, int k0, float* wb) {
-    chunk_io<false>(r, S, j0, k0, wb);
-}
-
 // ------------------------------------------------------------------------------ the contraction
 struct Stream {           // chunk pipeline state carried from one product to the next
     float r[16];          // prefetched first chunk of the next product
+    float rb[4];          //   (+ its bias entries)
     float* wbuf;          // two chunk buffers
     int par;              // which one the next chunk goes to
     int n;                // diagnostic build: stamps written so far
 };
+__device__ __forceinline__ void chunk_load(Stream& St, const BSrc& S, int j0, int k0) {
+    if (S.kind != SRC_NONE) chunk_io<true>(St.r, St.rb, S, j0, k0, nullptr);
+}
+__device__ __forceinline__ void chunk_store(Stream& St, const BSrc& S, int j0, int k0, float* wb) {
+    chunk_io<false>(St.r, St.rb, S, j0, k0, wb);
+}
 
 // out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RT (RT <= RTE row tiles), j < Jn, k < Kc.
 // RTE (1, 2 or 4) fixes the wave -> tile map at compile time: wave w owns row tile w % RTE and the NTW = RTE column
 // tiles (w / RTE) + (4 / RTE) * t of every 64-column block, so the MFMA loop has no data-dependent control flow; tiles
 // and k-steps beyond the real extents multiply zero-filled chunk rows / columns (the epilogue drops them).
 // On entry St.r holds chunk (0, 0) of S; on exit it holds chunk (0, 0) of `next` (if any).
-// epi(rt, col0, acc): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3.
-template <int RTE, class EPI>
+// epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0), fetched
+// BEFORE the contraction so that global operands of the epilogue (pre-activations of the dgrad mask) arrive under it.
+struct NoPre { __device__ __forceinline__ f32x4 operator()(int, int) const { return ZERO4; } };
+template <int RTE, class EPI, class PRE = NoPre>
 __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, int Jn, int Kc, const BSrc& next,
-                                          Stream& St, EPI&& epi) {
+                                          Stream& St, EPI&& epi, PRE&& pre = PRE()) {
     constexpr int WN = 4 / RTE, NTW = RTE;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -205,22 +216,22 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
     const bool active = rt < RT;
     const int K16 = up16(Kc);
     for (int j0 = 0; j0 < Jn; j0 += NCH) {
-        f32x4 acc[NTW];
+        f32x4 acc[NTW], aux[NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t] = ZERO4;
+        for (int t = 0; t < NTW; ++t) { acc[t] = ZERO4; aux[t] = active ? pre(rt, j0 + 16 * (cg + WN * t)) : ZERO4; }
         for (int k0 = 0; k0 < K16; k0 += KCH) {
             const int nk = min(KCH, K16 - k0) >> 4;
             float* wb = St.wbuf + St.par * CHUNK;
             St.par ^= 1;
             MSTAMP(1);
-            chunk_store(St.r, S, j0, k0, wb);
+            chunk_store(St, S, j0, k0, wb);
             MSTAMP(2);
             __syncthreads();
             MSTAMP(3);
             // prefetch: next k chunk, else next column block, else the following product's first chunk
-            if (k0 + KCH < K16) chunk_load(St.r, S, j0, k0 + KCH);
-            else if (j0 + NCH < Jn) chunk_load(St.r, S, j0 + NCH, 0);
-            else chunk_load(St.r, next, 0, 0);
+            if (k0 + KCH < K16) chunk_load(St, S, j0, k0 + KCH);
+            else if (j0 + NCH < Jn) chunk_load(St, S, j0 + NCH, 0);
+            else chunk_load(St, next, 0, 0);
             MSTAMP(4);
             if (active) {
                 const float* ap = A + (16 * rt + c) * lda + k0 + 4 * q;
@@ -249,7 +260,7 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
         MSTAMP(5);
         if (active) {
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) epi(rt, j0 + 16 * (cg + WN * t), acc[t]);
+            for (int t = 0; t < NTW; ++t) epi(rt, j0 + 16 * (cg + WN * t), acc[t], aux[t]);
         }
         MSTAMP(6);
     }
@@ -273,7 +284,7 @@ __device__ __forceinline__ BSrc src_none() {
 __device__ __forceinline__ BSrc src_w(const Layout& L, const MlpDesc& D, const float* P, int li, bool holey) {
     BSrc S = src_none();
     S.kind = SRC_W; S.p = P + D.w_off[li]; S.d2 = D.b_off[li] - D.w_off[li];
-    S.J1 = S.J = D.dout[li]; S.K = D.din[li]; S.ld = D.din[li];
+    S.J1 = S.J = D.dout[li]; S.K = D.din[li]; S.ld = D.din[li]; S.lim = (unsigned)(L.n_params - D.w_off[li]);
     if (holey) { S.hole0 = L.dd; S.hole = L.uoff - L.dd; }
     return S;
 }
@@ -300,7 +311,7 @@ __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const 
         } else {
             float* dst = (li & 1) ? X.h1 : X.h0;
             float* preT = X.wsm + D.pre_off[li] + X.row0;
-            tile_gemm<RTE>(cur, ldc, RTE, S, N, Kc, nx, St, [&](int rt, int col0, const f32x4& acc) {
+            tile_gemm<RTE>(cur, ldc, RTE, S, N, Kc, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                 const int n = col0 + c;
                 if (n < N) {
                     const int r0 = 16 * rt + 4 * q;
@@ -340,9 +351,9 @@ __global__ __launch_bounds__(NT) void k_fwd_enc(Layout L, const float* __restric
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 0;
     MSTAMP(100);
-    chunk_load(St.r, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), 0, 0);
+    chunk_load(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), 0, 0);
 
-    for (int i = tid; i < L.smem_enc / 4 - 2 * CHUNK; i += NT) xin[i] = 0.f;
+    for (int i = 4 * tid; i < L.smem_enc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(xin + i) = ZERO4;
     __syncthreads();
     for (int idx = tid; idx < TR * (L.dd + L.M); idx += NT) {
         const int r = idx / (L.dd + L.M), k = idx - r * (L.dd + L.M);
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_fwd_enc(Layout L, const float* __restric
     X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.RT = TR >> 4; X.h0 = h0; X.h1 = h1;
     float* out = wsm + (m == IVAE_MLP_G ? L.ws.g : m == IVAE_MLP_LOGV ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
     mlp_fwd<RTE>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
-                 [&](int rt, int col0, const f32x4& acc) {
+                 [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                      const int n = col0 + c;
                      if (n < L.dl) {
 #pragma unroll
@@ -393,7 +404,7 @@ __device__ __forceinline__ BSrc bwd_src(const Layout& L, const BwdCtx& X, const 
         S.kind = SRC_WT; S.p = X.P + D.w_off[li]; S.J1 = S.J = D.din[li]; S.K = D.dout[li]; S.ld = D.din[li];
     } else if (li > 0) {
         S.kind = SRC_PRE; S.p = X.wsm + D.pre_off[li - 1] + X.row0; S.J1 = S.J = D.din[li]; S.K = X.nrows; S.ld = L.Bp;
-        S.act = L.act; S.slope = L.slope;
+        S.act = L.act; S.slope = L.slope; { const long lim = L.ws.per_model - (D.pre_off[li - 1] + X.row0); S.lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
     } else {
         S.kind = SRC_ROWS; S.p = in_a; S.d2 = in_b ? in_b - in_a : 0L; S.J1 = na; S.J = na + nb; S.K = X.nrows;
         S.ld = na; S.ld2 = nb;
@@ -427,7 +438,7 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                 BSrc nx2 = nx;
                 if (more) nx2 = S;
                 tile_gemm<4>(X.dT + rc * 16 * L.ldr, L.ldr, min(4, NTl - rc), S, K + 1, X.TR, nx2, St,
-                          [&](int rt, int col0, const f32x4& acc) {
+                          [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                               const int k = col0 + c;
 #pragma unroll
                               for (int r = 0; r < 4; ++r) {
@@ -445,11 +456,10 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
             if (li > 0) {
                 float* dnx = cur ? X.d0 : X.d1;
                 const float* preT = X.wsm + D.pre_off[li - 1] + X.row0;
-                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc) {
+                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
                     const int k = col0 + c;
                     if (k < K) {
                         const int r0 = 16 * rt + 4 * q;
-                        const f32x4 pre = *reinterpret_cast<const f32x4*>(preT + (size_t)k * L.Bp + r0);
                         f32x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -458,10 +468,13 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                         }
                         *reinterpret_cast<f32x4*>(X.dT + k * L.ldr + r0) = o;
                     }
+                }, [&](int rt, int col0) {
+                    const int k = min(col0 + c, K - 1);
+                    return *reinterpret_cast<const f32x4*>(preT + (size_t)k * L.Bp + 16 * rt + 4 * q);
                 });
                 cur ^= 1;
             } else {
-                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc) {
+                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                     const int k = col0 + c;
                     if (k < K) {
 #pragma unroll
@@ -508,8 +521,9 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
 
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 0;
-    chunk_load(St.r, (mode & 1) ? src_w(L, DF, P, 0, false) : bwd_first, 0, 0);
-    for (int i = tid; i < L.smem_dec / 4 - 2 * CHUNK; i += NT) t0[i] = 0.f;
+    MSTAMP(199);
+    chunk_load(St, (mode & 1) ? src_w(L, DF, P, 0, false) : bwd_first, 0, 0);
+    for (int i = 4 * tid; i < L.smem_dec / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(t0 + i) = ZERO4;
     __syncthreads();
 
     if (mode & 1) {
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
         FwdCtx X;
         X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.RT = TR >> 4; X.h0 = t0; X.h1 = t1;
         mlp_fwd<RTE>(L, X, DF, sz, lds, L.dl, false, (mode & 2) ? bwd_first : src_none(), St,
-                     [&](int rt, int col0, const f32x4& acc) {
+                     [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                          const int n = col0 + c;
                          if (n < L.dd) {
 #pragma unroll
@@ -567,6 +581,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
             wsm[L.ws.lp + row0 + r] = lp;
         }
     }
+    MSTAMP(200);
     if (mode & 2) {
         // dLoss/df = -a*w*(x-f)/var, all TR rows (zero beyond the batch): the tiles may hold forward activations
         const float w = 1.f / (float)C.global_batch;
@@ -578,6 +593,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
             dT[k * L.ldr + r] = v;
         }
         mlp_bwd<RTE>(L, B, DF, zrows, L.dl, nullptr, 0, sdz, lds, src_none(), St);
+        MSTAMP(201);
         __syncthreads();
         for (int idx = tid; idx < nrows * L.dl; idx += NT) {
             const int r = idx / L.dl, k = idx - r * L.dl;
@@ -620,9 +636,9 @@ __global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const floa
     const int nb = pri ? 0 : L.M;
 
     Stream St;
-    St.wbuf = wbuf; St.par = 0; St.n = 0;
-    chunk_load(St.r, bwd_src(L, X, L.mlp[m], 0, in_a, na, in_b, nb), 0, 0);
-    for (int i = tid; i < L.smem_benc / 4 - 2 * CHUNK; i += NT) dA[i] = 0.f;
+    St.wbuf = wbuf; St.par = 0; St.n = 1000;      // (diagnostic stamps of this kernel go to slots 1000..)
+    chunk_load(St, bwd_src(L, X, L.mlp[m], 0, in_a, na, in_b, nb), 0, 0);
+    for (int i = 4 * tid; i < L.smem_benc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dA + i) = ZERO4;
     __syncthreads();
     for (int idx = tid; idx < nrows * L.dl; idx += NT) {
         const int r = idx / L.dl, k = idx - r * L.dl;
@@ -646,6 +662,7 @@ __global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const floa
         dT[k * L.ldr + r] = dlt;
     }
     mlp_bwd<RTE>(L, X, L.mlp[m], in_a, na, in_b, nb, nullptr, 0, src_none(), St);
+    MSTAMP(202);
 }
 
 // Sum the per-tile slabs into grads and reduce the loss.  A block sums 64 parameters: wave g adds the tiles

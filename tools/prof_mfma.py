@@ -44,6 +44,8 @@ else:
 torch.cuda.synchronize()
 L.ivae_debug_set_prof_mf(C.c_void_p(0))
 b = buf.cpu().view(-1, 2).tolist()
+part = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # 0: slots 0..999 (k_fwd_enc / k_dec), 1: slots 1000.. (k_bwd_enc)
+b = b[1000 * part:1000 * part + 1000]
 b = [(i, t) for i, t in b if t]
 t0 = b[0][1]
 prev = t0
