@@ -144,3 +144,19 @@ def test_no_cpu_fallback():
         class Lap:
             name = 'laplace'
         ivae_amd.iVAE(3, 3, 4, prior=Lap())
+
+
+def test_pairwise_workspace_size_is_reported_without_a_gpu():
+    """ivae_pairwise_workspace_bytes is pure host arithmetic: positive for d <= 32 (sliced kernels), zero above
+    (wave-per-row kernels need none), error codes for bad shapes."""
+    import ctypes as C
+    L = _lib.lib()
+    n = C.c_size_t()
+    assert L.ivae_pairwise_workspace_bytes(1024, 1024, 5, C.byref(n)) == 0 and n.value > 0
+    small = n.value
+    assert L.ivae_pairwise_workspace_bytes(4096, 4096, 20, C.byref(n)) == 0 and n.value > small
+    assert L.ivae_pairwise_workspace_bytes(37, 512, 12, C.byref(n)) == 0 and n.value > 0
+    assert L.ivae_pairwise_workspace_bytes(64, 64, 40, C.byref(n)) == 0 and n.value == 0
+    assert L.ivae_pairwise_workspace_bytes(0, 64, 5, C.byref(n)) == -1
+    assert L.ivae_pairwise_workspace_bytes(64, 64, 65, C.byref(n)) == -4
+    assert L.ivae_pairwise_workspace_bytes(64, 64, 5, None) == -3

@@ -190,10 +190,12 @@ def test_module_works_with_stock_torch_adam_and_forward():
     assert torch.isfinite(e1) and z1.shape == (64, 10)
 
 
-def test_pairwise_rectangular_matches_oracle():
-    """Rows != columns (the data-parallel shard shape): ivae_pairwise vs explicit numpy."""
+@pytest.mark.parametrize("nr,nc,d", [(37, 101, 6), (300, 1111, 20), (513, 64, 32), (70, 130, 40), (1, 1, 1)])
+def test_pairwise_rectangular_matches_oracle(nr, nc, d):
+    """Rows != columns (the data-parallel shard shape): ivae_pairwise vs explicit numpy, for the sliced kernels
+    (d <= 32: several column / row slices, ragged last slice, d a multiple of 4 or not) and the wave-per-row kernels
+    (d = 40); the degenerate 1 x 1 x 1 problem too."""
     rng = np.random.RandomState(3)
-    nr, nc, d = 37, 101, 6
     z = rng.randn(nr, d).astype(np.float32)
     g = rng.randn(nc, d).astype(np.float32)
     v = np.exp(0.3 * rng.randn(nc, d)).astype(np.float32)
