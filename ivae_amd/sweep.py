@@ -1,0 +1,179 @@
+"""Paper-style sweep (BASELINE configs[4]): many independent iVAE runs -- seeds x latent dimensions -- packed as
+batched-model launches, a disjoint set of runs per GPU, no data-path collective; every run is scored by the Mean
+Correlation Coefficient with the correlation matrix computed on the GPU and the Hungarian step on the host.
+
+    python -m ivae_amd.sweep --dims 5,10,20,40 --seeds 64 --epochs 20                       # one GPU
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m ivae_amd.sweep --dims ... --seeds 64
+
+Each run is what `main.py --config ivae.yaml`-style experiments do per seed (runners/ivae.py:31-123 with the
+`iVAE` class of models/nets.py:391-486): its own dataset (data/data.py generator semantics, seed = run seed), its
+own xavier-initialised model (seed = run seed), `epochs` passes of shuffled batches of 64 with Adam, then the
+full-data evaluation on a *sampled* z (runners/ivae.py:118-123).  Runs of one latent dimension form one pack:
+the fused persistent kernel where it covers the shape, the generic MFMA kernels otherwise.
+"""
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from scipy.optimize import linear_sum_assignment
+
+from . import ops
+from .data import generate_data
+from .dist import gather_model_results, model_range
+from .trainer import FusedPackedTrainer, PackedTrainer
+
+
+def device_datasets(n_models, n_seg, n_per_seg, d, seeds, device):
+    """Piecewise-stationary nonlinear-ICA data with the generator semantics of data/data.py:134-304 (gaussian
+    sources modulated per segment by L ~ U(.5, 3), 3-layer lrelu mixing with column-normalised uniform matrices,
+    without the condition-number rejection step), drawn on the device, one generator seed per run.
+    Returns x (n, N, d), u (n, N, n_seg) one-hot, s (n, N, d)."""
+    N = n_seg * n_per_seg
+    xs, ss = [], []
+    for sd in seeds:
+        g = torch.Generator(device=device).manual_seed(int(sd))
+        L = torch.rand(n_seg, 1, d, generator=g, device=device) * 2.5 + 0.5
+        s = (torch.randn(n_seg, n_per_seg, d, generator=g, device=device) * L).reshape(N, d)
+        A = torch.rand(d, d, generator=g, device=device) * 2 - 1
+        A = A / A.pow(2).sum(0, keepdim=True).sqrt()
+        x = s
+        for layer in range(3):
+            x = x @ A
+            if layer < 2:
+                x = torch.where(x > 0, x, 0.1 * x)
+        xs.append(x)
+        ss.append(s)
+    lab = torch.arange(n_seg, device=device).repeat_interleave(n_per_seg)
+    u = torch.zeros(N, n_seg, device=device)
+    u[torch.arange(N, device=device), lab] = 1
+    return torch.stack(xs).contiguous(), u.unsqueeze(0).expand(n_models, N, n_seg).contiguous(), torch.stack(ss).contiguous()
+
+
+def host_datasets(n_seg, n_per_seg, d, seeds, device):
+    """The bit-exact host generator (ivae_amd.data.generate_data == data/data.py:200-304, repeat_linearity=True as
+    data.py:369), one dataset per run seed."""
+    xs, us, ss = [], [], []
+    for sd in seeds:
+        S, X, U, _, _ = generate_data(n_per_seg, n_seg, d, n_layers=3, seed=int(sd), prior='gauss', activation='lrelu',
+                                      repeat_linearity=True)
+        xs.append(torch.from_numpy(np.ascontiguousarray(X, np.float32)))
+        us.append(torch.from_numpy(np.ascontiguousarray(U, np.float32)))
+        ss.append(torch.from_numpy(np.ascontiguousarray(S, np.float32)))
+    return torch.stack(xs).to(device), torch.stack(us).to(device), torch.stack(ss).to(device)
+
+
+def evaluate_pack(shape, params, x, u, s_true, rows_per_call=8192, seed=0):
+    """Full-data MCC of every model of a pack: z sampled through ivae_forward in row blocks (all models per launch),
+    correlation blocks by ivae_corr on the device, assignment on the host (metrics/mcc.py:326-335).
+    Returns (n_models,) float64 numpy."""
+    n, N, _ = x.shape
+    dev = x.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ws = ops.Workspace()
+    z = torch.empty(n, N, shape.latent_dim, device=dev)
+    for lo in range(0, N, rows_per_call):
+        hi = min(N, lo + rows_per_call)
+        eps = torch.randn(n, hi - lo, shape.latent_dim, generator=g, device=dev)
+        co = ops.make_coef(N=float(N), global_batch=hi - lo)
+        z[:, lo:hi] = ops.forward(shape, co, params, x[:, lo:hi].contiguous(),
+                                  u[:, lo:hi].contiguous() if u is not None else None, eps, ws, n)
+    cc = torch.stack([ops.corr(s_true[m], z[m]) for m in range(n)]).abs().cpu().numpy()    # one host copy per pack
+    return np.array([c[linear_sum_assignment(-c)].mean() for c in cc])
+
+
+def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2, hidden=50, data="device",
+              device=None, rank=0, world=1, log=None):
+    """Runs this rank's share of the (dim, seed) grid; returns (local run ids, local MCCs, seconds spent training,
+    training steps x models done)."""
+    device = device or torch.device("cuda", 0)
+    runs = [(d, s) for d in dims for s in range(n_seeds)]
+    lo, hi = model_range(len(runs), rank, world)
+    mine = runs[lo:hi]
+    mcc_local = np.zeros(hi - lo)
+    t_train, work = 0.0, 0
+    N = n_seg * n_per_seg
+    for d in sorted({r[0] for r in mine}):
+        idx = [i for i, r in enumerate(mine) if r[0] == d]
+        seeds = [mine[i][1] for i in idx]
+        shape = ops.ModelShape(d, d, n_seg, hidden, 3, "lrelu", .1)
+        if data == "host":
+            x, u, s_true = host_datasets(n_seg, n_per_seg, d, seeds, device)
+        else:
+            x, u, s_true = device_datasets(len(seeds), n_seg, n_per_seg, d, [1000 * d + s for s in seeds], device)
+        fused = ops.train_steps_supported(shape, batch)
+        cls = FusedPackedTrainer if fused else PackedTrainer
+        tr = cls(shape, n_models=len(seeds), batch=batch, lr=lr, seed=1000 * d + seeds[0], device=device)
+        tr.set_data(x, u)
+        steps = epochs * (N // batch)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        if fused:
+            tr.run(steps)
+        else:
+            for _ in range(steps):
+                tr.step()
+        torch.cuda.synchronize(device)
+        t_train += time.perf_counter() - t0
+        work += steps * len(seeds)
+        m = evaluate_pack(shape, tr.params, x, u, s_true, seed=d)
+        mcc_local[idx] = m
+        if log:
+            log("rank %d: d=%d, %d runs, %s, %d steps: MCC mean %.3f (min %.3f, max %.3f)" % (
+                rank, d, len(seeds), "fused" if fused else "generic", steps, m.mean(), m.min(), m.max()))
+    return (lo, hi), mcc_local, t_train, work
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--dims", default="5,10,20,40")
+    ap.add_argument("--seeds", type=int, default=64, help="runs per latent dimension")
+    ap.add_argument("--epochs", type=int, default=20)
+    ap.add_argument("--nps", type=int, default=1000, help="samples per segment")
+    ap.add_argument("--ns", type=int, default=40, help="segments")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--lr", type=float, default=1e-2)
+    ap.add_argument("--data", choices=["device", "host"], default="device",
+                    help="host: the bit-exact numpy generator of data/data.py (seconds per dataset); device: same "
+                         "semantics drawn on the GPU")
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    dims = [int(t) for t in args.dims.split(",")]
+    t0 = time.perf_counter()
+    (lo, hi), mcc, t_train, work = run_sweep(dims, args.seeds, args.epochs, args.ns, args.nps, args.batch, args.lr,
+                                             data=args.data, device=dev, rank=rank, world=world,
+                                             log=lambda s: print(s, flush=True))
+    n_runs = len(dims) * args.seeds
+    allm = gather_model_results(torch.from_numpy(mcc).to(dev), n_runs).cpu().numpy()
+    stats = torch.tensor([t_train, float(work)], device=dev, dtype=torch.float64)
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        t_train = float(tmax[0])
+        work = float(stats[1])
+    if rank == 0:
+        per_dim = {}
+        for i, d in enumerate(dims):
+            m = allm[i * args.seeds:(i + 1) * args.seeds]
+            per_dim[str(d)] = {"mcc_mean": round(float(m.mean()), 4), "mcc_std": round(float(m.std()), 4)}
+        print(json.dumps({"sweep": "iVAE seeds x dims, packed runs", "n_runs": n_runs, "n_gpus": world,
+                          "epochs": args.epochs, "batch": args.batch, "data": args.data,
+                          "train_samples_per_s": round(work * args.batch / t_train, 1),
+                          "train_seconds_max_over_ranks": round(t_train, 2),
+                          "wall_seconds": round(time.perf_counter() - t0, 2), "mcc": per_dim}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
