@@ -270,7 +270,7 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
 struct FwdCtx {
     const float* P;        // this model's parameters
     float* wsm;            // this model's workspace
-    int row0, nrows, RT;
+    int row0, nrows;
     float* h0;             // hidden tiles (TR, ldh), column H = 1
     float* h1;
 };
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NT) void k_fwd_enc(Layout L, const float* __restric
     }
     // (the first tile_gemm's barrier orders these writes before any operand read)
     FwdCtx X;
-    X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.RT = TR >> 4; X.h0 = h0; X.h1 = h1;
+    X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = h0; X.h1 = h1;
     float* out = wsm + (m == IVAE_MLP_G ? L.ws.g : m == IVAE_MLP_LOGV ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
     mlp_fwd<RTE>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
                  [&](int rt, int col0, const f32x4& acc, const f32x4&) {
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
             sz[r * lds + k] = zz;
         }
         FwdCtx X;
-        X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.RT = TR >> 4; X.h0 = t0; X.h1 = t1;
+        X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = t0; X.h1 = t1;
         mlp_fwd<RTE>(L, X, DF, sz, lds, L.dl, false, (mode & 2) ? bwd_first : src_none(), St,
                      [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                          const int n = col0 + c;
