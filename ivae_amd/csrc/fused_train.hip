@@ -1034,7 +1034,10 @@ static hipError_t launch_cfg(const FusedArgs& A, int n_models, hipStream_t st) {
 }
 
 #ifndef FT_SHAPES
-#define FT_SHAPES(X) X(10, 10, 40, 50) X(10, 10, 0, 50) X(5, 5, 40, 50) X(5, 5, 0, 50)
+// d = 4..10 with 40 segments (the LDS holds no more: d = 11 overflows) and their VAE counterparts
+#define FT_SHAPES(X)                                                                                                  \
+    X(10, 10, 40, 50) X(10, 10, 0, 50) X(5, 5, 40, 50) X(5, 5, 0, 50) X(4, 4, 40, 50) X(4, 4, 0, 50) X(6, 6, 40, 50)        \
+    X(6, 6, 0, 50) X(7, 7, 40, 50) X(7, 7, 0, 50) X(8, 8, 40, 50) X(8, 8, 0, 50) X(9, 9, 40, 50) X(9, 9, 0, 50)
 #endif
 
 #ifdef FT_PROF

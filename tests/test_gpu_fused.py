@@ -81,7 +81,8 @@ def test_fused_steps_match_oracle(name, n_steps):
             assert relmax(z[m].cpu().numpy(), zl) < 1e-5
 
 
-@pytest.mark.parametrize("dd,dl,M", [(5, 5, 40), (5, 5, 0)])
+@pytest.mark.parametrize("dd,dl,M", [(5, 5, 40), (5, 5, 0), (4, 4, 40), (6, 6, 40), (7, 7, 40), (7, 7, 0), (8, 8, 40),
+                                      (8, 8, 0), (9, 9, 40), (9, 9, 0)])
 def test_fused_odd_dims_match_oracle(dd, dl, M):
     """d = 5: u sits behind a hole column of the encoder input tile, heads are 5 wide (the d = 5 end of the
     BASELINE configs[4] sweep).  No reference fixture at this shape: parity is against the fp64 oracle, which the
@@ -112,12 +113,13 @@ def test_fused_odd_dims_match_oracle(dd, dl, M):
         assert relmax(z[m].cpu().numpy(), zl) < 1e-3
 
 
-def test_fused_first_step_moments_odd_dims():
-    """One step at d = 5: exp_avg = 0.1 * grad, so every gradient (hole column included) is checked to 1e-5."""
+@pytest.mark.parametrize("dim", [4, 5, 6, 7, 8, 9])
+def test_fused_first_step_moments_odd_dims(dim):
+    """One step at d = 4..9: exp_avg = 0.1 * grad, so every gradient (hole column included) is checked to 1e-5."""
     from oracle import torch_ref
-    spec = np_ref.Spec(5, 5, 40)
+    spec = np_ref.Spec(dim, dim, 40)
     names = spec.param_names()
-    shape = ops.ModelShape(5, 5, 40, 50, 3, "lrelu", .1)
+    shape = ops.ModelShape(dim, dim, 40, 50, 3, "lrelu", .1)
     X, U, idx, eps = make_problem(spec, 1, 1, seed=12)
     P0 = {k: v.numpy() for k, v in torch_ref.xavier_params(spec, seed=3).items()}
     d = torch.device("cuda:0")
