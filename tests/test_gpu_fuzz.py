@@ -1,0 +1,70 @@
+"""Randomised shapes through ivae_elbo_fwd_bwd against the fp64 oracle: odd dimensions (1-wide heads, hidden widths
+that are not tile multiples, more than 64 / 128 hidden units -> several column and k chunks), 1..5 layers, every
+activation, ragged and single-row batches, with and without the pairwise terms, one and two packed models.
+No reference fixture exists at these shapes (said here); the oracle is pinned by the fixtures at others."""
+import numpy as np
+import pytest
+import torch
+
+from ivae_amd import ops
+from oracle import np_ref
+from tests.util import relmax
+
+pytestmark = pytest.mark.gpu
+
+ACTS = ["lrelu", "xtanh", "sigmoid", "none"]
+
+
+def _case(seed):
+    r = np.random.RandomState(1000 + seed)
+    dd = int(r.choice([1, 2, 3, 5, 10, 20, 33, 70]))
+    dl = int(r.choice([1, 2, 4, 5, 10, 12, 20, 33]))
+    M = int(r.choice([0, 1, 7, 40, 130]))
+    H = int(r.choice([1, 3, 17, 50, 64, 65, 100, 130, 200]))
+    L = int(r.choice([1, 2, 3, 5]))
+    act = ACTS[int(r.randint(4))]
+    B = int(r.choice([1, 2, 15, 16, 17, 63, 64, 65, 130, 300]))
+    pairwise = bool(r.randint(2))
+    n_models = int(r.choice([1, 2]))
+    return dd, dl, M, H, L, act, B, pairwise, n_models
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shape_matches_fp64_oracle(seed):
+    dd, dl, M, H, L, act, B, pairwise, n_models = _case(seed)
+    spec = np_ref.Spec(data_dim=dd, latent_dim=dl, aux_dim=M, hidden_dim=H, n_layers=L, activation=act, slope=.1,
+                       decoder_var=.1)
+    rng = np.random.RandomState(seed)
+    names = spec.param_names()
+    Ps, xs, us, es = [], [], [], []
+    for m in range(n_models):
+        P = {}
+        for mlp in spec.mlps:
+            for li, (i, o) in enumerate(spec.layer_dims(mlp)):
+                P[f"{mlp}.fc.{li}.weight"] = (rng.uniform(-1, 1, (o, i)) / np.sqrt(i)).astype(np.float32)
+                P[f"{mlp}.fc.{li}.bias"] = (rng.uniform(-1, 1, (o,)) / np.sqrt(i)).astype(np.float32)
+        Ps.append(P)
+        xs.append(rng.randn(B, dd).astype(np.float32))
+        us.append((rng.randn(B, M) * (rng.rand(B, M) < .3)).astype(np.float32))      # dense, not one-hot
+        es.append(rng.randn(B, dl).astype(np.float32))
+    coef = np_ref.Coef(a=3., b=2., c=1.5 if pairwise else 2., d=.5, N=5000., pairwise=pairwise)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    shape = ops.ModelShape(dd, dl, M, H, L, act, .1)
+    co = ops.make_coef(coef.a, coef.b, coef.c, coef.d, coef.N, spec.decoder_var, coef.pairwise, B)
+    flat = np.stack([np.concatenate([P[n].reshape(-1) for n in names]) for P in Ps])
+    loss, z, grads = ops.elbo_fwd_bwd(shape, co, t(flat), t(np.stack(xs)), t(np.stack(us)) if M else None,
+                                      t(np.stack(es)), ops.Workspace(), n_models=n_models)
+    g = grads.cpu().numpy()
+    for m in range(n_models):
+        fw = np_ref.elbo_forward(Ps[m], xs[m], us[m], es[m], spec, coef, np.float64)
+        G = np_ref.elbo_backward(Ps[m], xs[m], us[m], fw, spec, coef, np.float64)
+        ref = float(fw["loss"])
+        assert abs(float(loss[m]) - ref) <= 1e-5 * max(abs(ref), 1.0), (seed, m, float(loss[m]), ref)
+        assert relmax(z[m].cpu().numpy(), fw["z"]) < 1e-5
+        off = 0
+        for n in names:
+            r_ = G[n]
+            got = g[m, off:off + r_.size].reshape(r_.shape)
+            off += r_.size
+            assert np.abs(got - r_).max() <= 2e-5 * max(np.abs(r_).max(), 1e-3), (seed, m, n, np.abs(got - r_).max(), np.abs(r_).max())
