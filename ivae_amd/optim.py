@@ -14,6 +14,50 @@ from . import ops
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._flat = None        # (params tuple, flat_m, flat_v) of the direct path (step_flat)
+        self._flat_key = None    # the param list those were built for
+        self._pending = 0        # steps taken by step_flat not yet written to the per-parameter `step` entries
+
+    # -- direct path: the caller holds the flat parameter arena and the flat gradient ----------------------
+    def _sync_steps(self):
+        if self._pending:
+            for p in self._flat[0]:
+                self.state[p]['step'] += self._pending
+            self._pending = 0
+
+    def step_flat(self, flat_p, flat_g):
+        """One Adam update over a whole model whose parameters tile `flat_p` in `param_groups[0]` order, with the
+        gradient given as one flat buffer (what `ivae_elbo_fwd_bwd` returns): no per-parameter Python work.  The
+        per-parameter state (`step`, `exp_avg`, `exp_avg_sq`) stays what `state_dict()` of torch.optim.Adam holds."""
+        if len(self.param_groups) != 1:
+            raise RuntimeError('step_flat needs a single parameter group')
+        group = self.param_groups[0]
+        plist = group['params']
+        if self._flat is None or self._flat_key is not plist or len(plist) != len(self._flat[0]):
+            ps = tuple(plist)
+            self._sync_steps()
+            if any(len(self.state[p]) == 0 for p in ps):
+                self._init_group_state(list(ps))
+            m = self._flat_view([self.state[p]['exp_avg'] for p in ps])
+            v = self._flat_view([self.state[p]['exp_avg_sq'] for p in ps])
+            if m is None or v is None or m.numel() != flat_p.numel():
+                raise RuntimeError('optimizer state is not one flat buffer over these parameters')
+            self._flat, self._flat_key = (ps, m, v), plist
+            self._step0 = int(self.state[ps[0]]['step'])
+        self._pending += 1
+        b1, b2 = group['betas']
+        ops.adam_step(flat_p, self._flat[1], self._flat[2], flat_g, group['lr'], self._step0 + self._pending, b1, b2,
+                      group['eps'])
+
+    def state_dict(self):
+        self._sync_steps_keep()
+        return super().state_dict()
+
+    def _sync_steps_keep(self):
+        if self._pending:
+            n = self._pending
+            self._sync_steps()
+            self._step0 += n
 
     @staticmethod
     def _flat_view(tensors):
@@ -46,6 +90,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        self._sync_steps_keep()
+        self._flat = None
         loss = None
         if closure is not None:
             with torch.enable_grad():

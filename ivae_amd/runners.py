@@ -94,18 +94,18 @@ def runner(args, config):
                 c = 0
                 if epoch > config.epochs / 1.6:
                     a, b, c, d = 2 * config.a, 1, 1, 1
-            batches = _epoch_batches(N, B, True, device, gen)
+            # one gather per epoch (DataLoader(shuffle=True, drop_last=True), runners/ivae.py:25); batches are views
+            nb = N // B
+            perm = torch.randperm(N, device=device, generator=gen)[:nb * B]
+            Xe, Ue, Se = X[perm].view(nb, B, -1), U[perm].view(nb, B, -1), S[perm].view(nb, B, -1)
             loss_sum = torch.zeros((), device=device)
-            cc = torch.empty(len(batches), d_latent, d_latent, dtype=torch.float64, device=device)
-            for i, idx in enumerate(batches):
-                x, u, s_true = X[idx], U[idx], S[idx]
-                optimizer.zero_grad()
-                loss, z = model.elbo(x, u, N, a=a, b=b, c=c, d=d)
-                loss.backward()
-                loss_sum += loss.detach()
-                cc[i] = corr_matrix_gpu(s_true, z.detach())
-                optimizer.step()
-            train_loss = float(loss_sum.item()) / len(batches)          # the epoch's one sync
+            cc = torch.empty(nb, d_latent, d_latent, dtype=torch.float64, device=device)
+            for i in range(nb):
+                # zero_grad -> elbo -> backward -> step (runners/ivae.py:75-91) as one launch sequence
+                loss, z = model.direct_step(optimizer, Xe[i], Ue[i] if config.ica else None, a, b, c, d, N, True)
+                loss_sum += loss
+                cc[i] = corr_matrix_gpu(Se[i], z)
+            train_loss = float(loss_sum.item()) / nb          # the epoch's one sync
             train_perf = float(np.mean(_assignment_scores(cc.abs().cpu().numpy())))
             perf_hist.append(train_perf)
             loss_hist.append(train_loss)
