@@ -230,14 +230,17 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                 it += 1
                 if anneal:
                     model.anneal(N, max_iter, it)
-                optimizer.zero_grad()
-                x = X[bidx]
-                elbo, z_est = model.elbo(x, U[bidx]) if with_u else model.elbo(x)
-                elbo.mul(-1).backward()
-                optimizer.step()
-                logger.update('elbo', -elbo.detach())
+                # zero_grad -> elbo -> mul(-1).backward() -> step (wrappers.py:64-70) as one launch sequence; the loss
+                # coefficients are what model.elbo would pass (nets.py:457-475)
+                if with_u and model.anneal_params:
+                    a_, b_, c_, d_, N_ = model._training_hyperparams
+                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx], a_, b_, c_, d_, N_, True)
+                else:
+                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx] if with_u else None, 1., 1., 1., 1., 1.,
+                                                    False)
+                logger.update('elbo', loss)
                 if cc is not None:
-                    cc[i] = corr_matrix_gpu(z_est.detach(), Z[bidx])
+                    cc[i] = corr_matrix_gpu(z_est, Z[bidx])
         if cc is not None:
             for score in _assignment_scores(cc.abs().cpu().numpy()):
                 logger.update('perf', score)
