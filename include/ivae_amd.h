@@ -171,6 +171,12 @@ int ivae_corr_workspace_bytes(int64_t n, int32_t d, size_t* out);
 int ivae_corr(const float* x, const float* y, int64_t n, int32_t d, double* cc_out,
               void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same correlation block for n_blocks independent (n, d) problems stored back to back -- the per-step batch
+ * scores of a training epoch (runners/ivae.py:86, models/wrappers.py:75 call mcc once per step on the batch):
+ * x, y (n_blocks, n, d) fp32; cc_out (n_blocks, d, d) float64.  One launch, no workspace. */
+int ivae_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int32_t d,
+                      double* cc_out, void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------- */
 const char* ivae_last_hip_error(void);   /* text of the last failing HIP call (thread-local) */
 const char* ivae_version(void);

@@ -194,4 +194,13 @@ int ivae_corr(const float* x, const float* y, int64_t n, int32_t d, double* cc_o
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_corr");
 }
 
+int ivae_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int32_t d, double* cc_out,
+                      void* stream) {
+    if (!x || !y || !cc_out) return IVAE_E_NULLPTR;
+    if (n_blocks <= 0 || n < 2 || d <= 0) return IVAE_E_BADDIMS;
+    if (d > 64 || n_blocks > 0x7fffffff) return IVAE_E_TOOLARGE;
+    hipError_t e = launch_corr_batched(x, y, n_blocks, n, d, cc_out, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_corr_batched");
+}
+
 }  // extern "C"

@@ -103,6 +103,85 @@ __global__ __launch_bounds__(256) void k_corr_final(const double* __restrict__ p
     }
 }
 
+// Many small problems in ONE launch: block b owns rows [b*n, (b+1)*n) of x and y (the per-step batch scores of a
+// training epoch, runners/ivae.py:86, wrappers.py:75: n = batch size).  Same two-pass centred moments in float64,
+// everything inside the workgroup: column means -> centred 64-row chunks in LDS -> moments -> correlation block.
+__global__ __launch_bounds__(256) void k_corr_batched(const float* __restrict__ x, const float* __restrict__ y, int64_t n,
+                                                      int d, double* __restrict__ cc) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int ld = 2 * d + 1, nout = d * d + 2 * d;
+    double* tile = sm;                          // CORR_ROWS x (2d+1)
+    double* mean = tile + CORR_ROWS * ld;       // 2d
+    double* mom = mean + 2 * d;                 // d*d + 2d
+    double* red = mom + nout;                   // 256
+    const float* xb = x + (size_t)blockIdx.x * n * d;
+    const float* yb = y + (size_t)blockIdx.x * n * d;
+    {   // pass 1: column means
+        const int c = threadIdx.x % (2 * d), sub = threadIdx.x / (2 * d), nsub = 256 / (2 * d);
+        double acc = 0.0;
+        if (sub < nsub) {
+            const float* src = c < d ? xb + c : yb + (c - d);
+            for (int64_t r = sub; r < n; r += nsub) acc += (double)src[r * d];
+        }
+        red[threadIdx.x] = sub < nsub ? acc : 0.0;
+        __syncthreads();
+        if (threadIdx.x < 2 * d) {
+            double t = 0.0;
+            for (int s = 0; s < nsub; ++s) t += red[s * 2 * d + threadIdx.x];
+            mean[threadIdx.x] = t / (double)n;
+        }
+        __syncthreads();
+    }
+    double acc[17];
+#pragma unroll
+    for (int q = 0; q < 17; ++q) acc[q] = 0.0;
+    for (int64_t r0 = 0; r0 < n; r0 += CORR_ROWS) {
+        const int nr = (int)((n - r0) < CORR_ROWS ? (n - r0) : CORR_ROWS);
+        for (int idx = threadIdx.x; idx < CORR_ROWS * 2 * d; idx += 256) {
+            const int r = idx / (2 * d), c = idx - r * 2 * d;
+            double val = 0.0;
+            if (r < nr) val = (c < d ? (double)xb[(r0 + r) * d + c] : (double)yb[(r0 + r) * d + (c - d)]) - mean[c];
+            tile[r * ld + c] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 17; ++q) {
+            const int o = threadIdx.x + q * 256;
+            if (o < nout) {
+                int ca, cb;
+                if (o < d * d) { ca = o / d; cb = d + (o - ca * d); }
+                else { ca = cb = o - d * d; }
+                double s = 0.0;
+                for (int r = 0; r < nr; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
+                acc[q] += s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 17; ++q) {
+        const int o = threadIdx.x + q * 256;
+        if (o < nout) mom[o] = acc[q] / (double)(n - 1);
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < d * d; o += 256) {
+        const int a = o / d, b = o - a * d;
+        double c = mom[o] / sqrt(mom[d * d + a]);
+        c = c / sqrt(mom[d * d + d + b]);
+        cc[(size_t)blockIdx.x * d * d + o] = fmin(1.0, fmax(-1.0, c));
+    }
+}
+
+hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int d, double* cc, hipStream_t st) {
+    const size_t smem = sizeof(double) * ((size_t)CORR_ROWS * (2 * d + 1) + 2 * d + (size_t)d * d + 2 * d + 256);
+    if (smem > 64 * 1024) {      // d > ~40: above the default dynamic-LDS limit (rare; the attribute call is cheap)
+        hipError_t e = hipFuncSetAttribute((const void*)k_corr_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_corr_batched, dim3((unsigned)n_blocks), dim3(256), smem, st, x, y, n, d, cc);
+    return hipGetLastError();
+}
+
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st) {
     double* mean = ws;
     double* psum = mean + 2 * d;

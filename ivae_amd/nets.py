@@ -186,7 +186,7 @@ class _FusedModel(nn.Module):
         f = self._ws.view('f', B, sh.data_dim).clone()
         return f, g, v, z, l
 
-    def direct_step(self, optimizer, x, u, a, b, c, d, N, pairwise, eps=None):
+    def direct_step(self, optimizer, x, u, a, b, c, d, N, pairwise, eps=None, z_out=None):
         """zero_grad -> elbo -> backward -> optimizer.step() (runners/ivae.py:75-91) without the autograd and
         per-parameter optimizer machinery: ivae_elbo_fwd_bwd writes the flat gradient, `optimizer.step_flat`
         (ivae_amd.FusedAdam) consumes it.  Same kernels, same noise draw, same update as the drop-in sequence.
@@ -194,7 +194,7 @@ class _FusedModel(nn.Module):
         eps = self._eps(x, eps)
         coef = ops.make_coef(a, b, c, d, N, self._decoder_var_f, pairwise, x.shape[0])
         flat = self._flat_params()
-        loss, z, grads = ops.elbo_fwd_bwd(self._shape, coef, flat, x, u, eps, self._ws)
+        loss, z, grads = ops.elbo_fwd_bwd(self._shape, coef, flat, x, u, eps, self._ws, z_out=z_out)
         optimizer.step_flat(flat, grads)
         return loss[0], z
 

@@ -103,8 +103,9 @@ class Workspace:
         return t.view(batch, width) if width else t
 
 
-def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1):
-    """ivae_elbo_fwd_bwd: -> (loss (n_models,), z, grads flat like params)."""
+def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, z_out=None):
+    """ivae_elbo_fwd_bwd: -> (loss (n_models,), z, grads flat like params).  z_out: write z there (a contiguous fp32
+    tensor of z's shape, e.g. one row block of an epoch's buffer) instead of allocating."""
     x = _f32c(x, "x")
     eps = _f32c(eps, "eps")
     params = _f32c(params, "params")
@@ -117,7 +118,13 @@ def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1):
     dev = x.device
     with torch.cuda.device(dev):
         buf = ws.get(dims, dev)
-        z = torch.empty(x.shape[:-1] + (shape.latent_dim,), dtype=torch.float32, device=dev)
+        if z_out is None:
+            z = torch.empty(x.shape[:-1] + (shape.latent_dim,), dtype=torch.float32, device=dev)
+        else:
+            z = z_out
+            if (z.dtype != torch.float32 or not z.is_contiguous() or z.device != dev
+                    or tuple(z.shape) != tuple(x.shape[:-1]) + (shape.latent_dim,)):
+                raise ValueError("z_out must be a contiguous float32 tensor of z's shape on the inputs' device")
         loss = torch.empty(n_models, dtype=torch.float32, device=dev)
         grads = torch.empty_like(params)
         check(_lib.lib().ivae_elbo_fwd_bwd(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps),
@@ -207,6 +214,19 @@ def corr(x, y):
         cc = torch.empty(d, d, dtype=torch.float64, device=dev)
         check(_lib.lib().ivae_corr(_ptr(x), _ptr(y), n, d, _ptr(cc), _ptr(ws), ws.numel() * 8, _stream(dev)),
               "ivae_corr")
+    return cc
+
+
+def corr_batched(x, y):
+    """ivae_corr_batched: (n_blocks, n, d) fp32 pairs -> (n_blocks, d, d) float64 correlation blocks, one launch."""
+    x, y = _f32c(x, "x"), _f32c(y, "y")
+    if x.shape != y.shape or x.dim() != 3:
+        raise ValueError("x and y must be (n_blocks, n, d) tensors of one shape")
+    nb, n, d = x.shape
+    dev = x.device
+    with torch.cuda.device(dev):
+        cc = torch.empty(nb, d, d, dtype=torch.float64, device=dev)
+        check(_lib.lib().ivae_corr_batched(_ptr(x), _ptr(y), nb, n, d, _ptr(cc), _stream(dev)), "ivae_corr_batched")
     return cc
 
 

@@ -99,12 +99,13 @@ def runner(args, config):
             perm = torch.randperm(N, device=device, generator=gen)[:nb * B]
             Xe, Ue, Se = X[perm].view(nb, B, -1), U[perm].view(nb, B, -1), S[perm].view(nb, B, -1)
             loss_sum = torch.zeros((), device=device)
-            cc = torch.empty(nb, d_latent, d_latent, dtype=torch.float64, device=device)
+            Ze = torch.empty(nb, B, d_latent, device=device)
             for i in range(nb):
                 # zero_grad -> elbo -> backward -> step (runners/ivae.py:75-91) as one launch sequence
-                loss, z = model.direct_step(optimizer, Xe[i], Ue[i] if config.ica else None, a, b, c, d, N, True)
+                loss, _ = model.direct_step(optimizer, Xe[i], Ue[i] if config.ica else None, a, b, c, d, N, True,
+                                            z_out=Ze[i])
                 loss_sum += loss
-                cc[i] = corr_matrix_gpu(Se[i], z)
+            cc = ops.corr_batched(Se, Ze)       # the per-step batch scores (runners/ivae.py:86), one launch per epoch
             train_loss = float(loss_sum.item()) / nb          # the epoch's one sync
             train_perf = float(np.mean(_assignment_scores(cc.abs().cpu().numpy())))
             perf_hist.append(train_perf)
@@ -215,9 +216,9 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
             drv.group['lr'] = scheduler.optimizer.param_groups[0]['lr']
             loss, zs = drv.full_batches(X, U, idx)
             logger.update('elbo', loss.sum(), weight=n_full)
-            if cc is not None:
-                for i in range(n_full):
-                    cc[i] = corr_matrix_gpu(zs[i], Z[batches[i]])
+            if cc is not None and n_full:       # the per-step batch scores (wrappers.py:75), one launch per epoch
+                cc[:n_full] = ops.corr_batched(zs.reshape(n_full, batch_size, d).contiguous(),
+                                               Z[idx.long().view(-1)].view(n_full, batch_size, d))
             it += n_full
             for i in range(n_full, len(batches)):
                 l1, z1 = drv.ragged_batch(X[batches[i]], None if U is None else U[batches[i]])
@@ -226,21 +227,27 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                     cc[i] = corr_matrix_gpu(z1, Z[batches[i]])
                 it += 1
         else:
+            n_full = N // batch_size
+            Ze = torch.empty(n_full, batch_size, d, device=device) if cc is not None else None
             for i, bidx in enumerate(batches):
                 it += 1
+                full = Ze is not None and i < n_full
                 if anneal:
                     model.anneal(N, max_iter, it)
                 # zero_grad -> elbo -> mul(-1).backward() -> step (wrappers.py:64-70) as one launch sequence; the loss
                 # coefficients are what model.elbo would pass (nets.py:457-475)
+                zo = Ze[i] if full else None
                 if with_u and model.anneal_params:
                     a_, b_, c_, d_, N_ = model._training_hyperparams
-                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx], a_, b_, c_, d_, N_, True)
+                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx], a_, b_, c_, d_, N_, True, z_out=zo)
                 else:
                     loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx] if with_u else None, 1., 1., 1., 1., 1.,
-                                                    False)
+                                                    False, z_out=zo)
                 logger.update('elbo', loss)
-                if cc is not None:
+                if cc is not None and not full:
                     cc[i] = corr_matrix_gpu(z_est, Z[bidx])
+            if Ze is not None and n_full:
+                cc[:n_full] = ops.corr_batched(Ze, Z[torch.stack(batches[:n_full]).view(-1)].view(n_full, batch_size, d))
         if cc is not None:
             for score in _assignment_scores(cc.abs().cpu().numpy()):
                 logger.update('perf', score)

@@ -352,3 +352,19 @@ def test_large_batch_against_fp64_oracle(family, B, dims):
         ref = G[n]
         assert relmax(g[off:off + ref.size].reshape(ref.shape), ref) < TOL, (n, relmax(g[off:off + ref.size].reshape(ref.shape), ref))
         off += ref.size
+
+
+@pytest.mark.parametrize("nb,n,d", [(7, 64, 5), (3, 70, 20), (2, 300, 64), (1, 2, 1)])
+def test_corr_batched_matches_numpy_corrcoef(nb, n, d):
+    """ivae_corr_batched: every block equals np.corrcoef(x, y, rowvar=False)[:d, d:] (metrics/mcc.py:328) in float64,
+    and the single-problem entry point ivae_corr, to 1e-12."""
+    rng = np.random.RandomState(nb * 100 + d)
+    x = rng.randn(nb, n, d).astype(np.float32)
+    y = (0.5 * x[..., ::-1] + rng.randn(nb, n, d)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    cc = ops.corr_batched(t(x), t(y)).cpu().numpy()
+    for b in range(nb):
+        ref = np.corrcoef(x[b].astype(np.float64), y[b].astype(np.float64), rowvar=False)[:d, d:]
+        assert np.abs(cc[b] - ref).max() < 1e-12
+        one = ops.corr(t(x[b]), t(y[b])).cpu().numpy()
+        assert np.abs(cc[b] - one).max() < 1e-12
