@@ -85,7 +85,7 @@ int ivae_pairwise(int32_t n_rows, int32_t n_cols, int32_t latent_dim, const Ivae
     if (need > 0 && !workspace) return IVAE_E_NULLPTR;
     if (workspace_bytes < need) return IVAE_E_WORKSPACE;
     hipError_t e = launch_pairwise(n_rows, n_cols, latent_dim, *coef, z, g_cols, v_cols, lq, lqi, lse_s, lse_k, rz, cg,
-                                   cv, (float*)workspace, (hipStream_t)stream);
+                                   cv, (float*)workspace, 1, 0, (hipStream_t)stream);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_pairwise");
 }
 
@@ -115,14 +115,12 @@ int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* p
     // the decoder's backward rides in the decoder's forward launch (it needs nothing from other rows)
     hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, grads, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "ivae_elbo_fwd_bwd");
-    if (coef->pairwise) {
-        for (int m = 0; m < L.n_models; ++m) {
-            float* w = (float*)workspace + (size_t)m * L.ws.per_model;
-            rc = ivae_pairwise(L.B, L.B, L.dl, coef, w + L.ws.z, w + L.ws.g, w + L.ws.v, w + L.ws.lq, w + L.ws.lqi,
-                               w + L.ws.lse_s, w + L.ws.lse_k, w + L.ws.rz, w + L.ws.cg, w + L.ws.cv, w + L.ws_pair,
-                               pairwise_ws_floats(L.B, L.B, L.dl) * sizeof(float), stream);
-            if (rc) return rc;
-        }
+    if (coef->pairwise) {       // all packed models in one launch sequence (their arrays repeat with the workspace stride)
+        float* w = (float*)workspace;
+        e = launch_pairwise(L.B, L.B, L.dl, *coef, w + L.ws.z, w + L.ws.g, w + L.ws.v, w + L.ws.lq, w + L.ws.lqi,
+                            w + L.ws.lse_s, w + L.ws.lse_k, w + L.ws.rz, w + L.ws.cg, w + L.ws.cv, w + L.ws_pair,
+                            L.n_models, (size_t)L.ws.per_model, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ivae_elbo_fwd_bwd");
     }
     e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, true, (hipStream_t)stream);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_elbo_fwd_bwd");

@@ -800,7 +800,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         }
         lds_barrier(); STAMP(2);
         // ---- F2: h2g -> T2, h2v -> T4; next batch's rows start to arrive in registers
+#ifndef FT_ABL_NOXU            // timing experiment only: every step re-uses the first batch
         load_xu<C>(xu, next_row, xd, ud);
+#endif
         {
             const int ln = opaque_lane();
             const float* const Wg[1] = {arena + C::off_of(L_G1)};

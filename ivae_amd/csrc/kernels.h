@@ -9,7 +9,7 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
                            const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st);
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
                            const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
-                           float* cg, float* cv, float* ws, hipStream_t st);
+                           float* cg, float* cv, float* ws, int n_models, size_t mstride, hipStream_t st);
 size_t pairwise_ws_floats(int n_rows, int n_cols, int d);
 hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1, double b2,
                        double eps, int64_t step, hipStream_t st);

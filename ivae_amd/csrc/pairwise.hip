@@ -34,6 +34,8 @@ struct PairGeom {                  // host-computed slicing (pair_geometry)
     size_t o_rz;                   // (NS, d, n_rows)
     size_t o_cg, o_cv;             // (NR, d, n_cols)
     size_t total;                  // floats
+    int n_models;                  // packed models: blockIdx.x = model * (blocks per model) + block
+    size_t mstride;                // floats between consecutive models in EVERY array (inputs, outputs, scratch)
 };
 
 static PairGeom pair_geometry(int n_rows, int n_cols, int d) {
@@ -58,6 +60,7 @@ static PairGeom pair_geometry(int n_rows, int n_cols, int d) {
     G.o_cg = o; o += (size_t)G.NR * d * n_cols;
     G.o_cv = o; o += (size_t)G.NR * d * n_cols;
     G.total = o;
+    G.n_models = 1; G.mstride = 0;
     return G;
 }
 
@@ -93,13 +96,16 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ g, const fl
 // Per-slice statistics: max and sum-of-exp2 over the slice's columns, for every k and for the sum over k.
 template <int DP>
 __global__ __launch_bounds__(PB) void k_pair_stats(PairGeom P, const float* __restrict__ z, const float* __restrict__ g,
-                                                   const float* __restrict__ v, float* __restrict__ ws) {
+                                                   const float* __restrict__ v, float* __restrict__ ws, int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bx = blockIdx.x % gx;
+    const size_t mo = (size_t)(blockIdx.x / gx) * P.mstride;
+    z += mo; g += mo; v += mo; ws += mo;
     const int d = P.d, sl = blockIdx.y, j0 = sl * P.CS, nj = min(P.CS, P.n_cols - j0);
     float* G = sm; float* W2 = G + P.CS * DP; float* A2 = W2 + P.CS * DP;
     stage_cols<DP>(g, v, j0, nj, d, G, W2, A2);
     __syncthreads();
-    const int i = blockIdx.x * PB + threadIdx.x;
+    const int i = bx * PB + threadIdx.x;
     const int ic = min(i, P.n_rows - 1);
     float zi[DP], m[DP], s[DP];
 #pragma unroll
@@ -140,8 +146,10 @@ __global__ __launch_bounds__(PB) void k_pair_stats(PairGeom P, const float* __re
 
 // Merge the slices (log2 units in, natural-log LSE out): thread = (plane k <= d, row i).
 __global__ __launch_bounds__(PB) void k_pair_combine(PairGeom P, const float* __restrict__ ws,
-                                                     float* __restrict__ lse_s, float* __restrict__ lse_k) {
-    const int i = blockIdx.x * PB + threadIdx.x, k = blockIdx.y;
+                                                     float* __restrict__ lse_s, float* __restrict__ lse_k, int gx) {
+    const size_t mo = (size_t)(blockIdx.x / gx) * P.mstride;
+    ws += mo; lse_s += mo; lse_k += mo;
+    const int i = (blockIdx.x % gx) * PB + threadIdx.x, k = blockIdx.y;
     if (i >= P.n_rows) return;
     const size_t plane = (size_t)(P.d + 1) * P.n_rows, at = (size_t)k * P.n_rows + i;
     const float* pm = ws + P.o_pm + at;
@@ -163,17 +171,20 @@ template <int DP>
 __global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const float* __restrict__ z,
                                                    const float* __restrict__ g, const float* __restrict__ v,
                                                    const float* __restrict__ lse_s, const float* __restrict__ lse_k,
-                                                   float* __restrict__ ws) {
+                                                   float* __restrict__ ws, int gx) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bx = blockIdx.x % gx;
+    const size_t mo = (size_t)(blockIdx.x / gx) * P.mstride;
+    z += mo; g += mo; v += mo; lse_s += mo; lse_k += mo; ws += mo;
     const int d = P.d;
     const float cP = C.b - C.c, cQ = C.c - C.d;
     if (blockIdx.z == 0) {
-        if ((int)blockIdx.x * PB >= P.n_rows || (int)blockIdx.y >= P.NS) return;
+        if (bx * PB >= P.n_rows || (int)blockIdx.y >= P.NS) return;
         const int sl = blockIdx.y, j0 = sl * P.CS, nj = min(P.CS, P.n_cols - j0);
         float* G = sm; float* W2 = G + P.CS * DP; float* A2 = W2 + P.CS * DP;
         stage_cols<DP>(g, v, j0, nj, d, G, W2, A2);
         __syncthreads();
-        const int i = blockIdx.x * PB + threadIdx.x;
+        const int i = bx * PB + threadIdx.x;
         const int ic = min(i, P.n_rows - 1);
         float zi[DP], lk[DP], acc[DP];
 #pragma unroll
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const
                 if (k < d) pr[(size_t)k * P.n_rows] = acc[k] * (2.f * LN2);
         }
     } else {
-        if ((int)blockIdx.x * PB >= P.n_cols || (int)blockIdx.y >= P.NR) return;
+        if (bx * PB >= P.n_cols || (int)blockIdx.y >= P.NR) return;
         const int rs = blockIdx.y, i0 = rs * P.RS, ni = min(P.RS, P.n_rows - i0);
         float* Z = sm; float* LK = Z + P.RS * DP; float* LSs = LK + P.RS * DP;
         for (int e = threadIdx.x; e < ni * DP; e += PB) {
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const
         }
         for (int e = threadIdx.x; e < ni; e += PB) LSs[e] = lse_s[i0 + e] * LOG2E;
         __syncthreads();
-        const int j = blockIdx.x * PB + threadIdx.x;
+        const int j = bx * PB + threadIdx.x;
         const int jc = min(j, P.n_cols - 1);
         float gj[DP], wj[DP], aj[DP], ag[DP], av[DP];
 #pragma unroll
@@ -257,10 +268,12 @@ __global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const
 __global__ __launch_bounds__(PB) void k_pair_finish(PairGeom P, float logMN, const float* __restrict__ ws,
                                                     const float* __restrict__ lse_s, const float* __restrict__ lse_k,
                                                     float* __restrict__ lq, float* __restrict__ lqi, float* __restrict__ rz,
-                                                    float* __restrict__ cg, float* __restrict__ cv) {
+                                                    float* __restrict__ cg, float* __restrict__ cv, int gx) {
+    const size_t mo = (size_t)(blockIdx.x / gx) * P.mstride;
+    ws += mo; lse_s += mo; lse_k += mo; lq += mo; lqi += mo; rz += mo; cg += mo; cv += mo;
     const int which = blockIdx.z, k = blockIdx.y;
     const int n = which == 0 ? P.n_rows : P.n_cols, ns = which == 0 ? P.NS : P.NR;
-    const int i = blockIdx.x * PB + threadIdx.x;
+    const int i = (blockIdx.x % gx) * PB + threadIdx.x;
     if (i >= n) return;
     if (which == 0 && k == 0) {          // lq, lqi of row i from the merged statistics
         float acc = 0.f;
@@ -284,12 +297,13 @@ static hipError_t launch_sliced(const PairGeom& P, const IvaeCoef& C, float logM
     const int rb = (P.n_rows + PB - 1) / PB, cb = (P.n_cols + PB - 1) / PB;
     const size_t sm_cols = (size_t)3 * P.CS * DP * sizeof(float);
     const size_t sm_rows = (size_t)(2 * P.RS * DP + P.RS) * sizeof(float);
-    hipLaunchKernelGGL(k_pair_stats<DP>, dim3(rb, P.NS), dim3(PB), sm_cols, st, P, z, g, v, ws);
-    hipLaunchKernelGGL(k_pair_combine, dim3(rb, d + 1), dim3(PB), 0, st, P, ws, lse_s, lse_k);
+    const int nm = P.n_models;
+    hipLaunchKernelGGL(k_pair_stats<DP>, dim3(rb * nm, P.NS), dim3(PB), sm_cols, st, P, z, g, v, ws, rb);
+    hipLaunchKernelGGL(k_pair_combine, dim3(rb * nm, d + 1), dim3(PB), 0, st, P, ws, lse_s, lse_k, rb);
     const int gx = rb > cb ? rb : cb, gy = P.NS > P.NR ? P.NS : P.NR;
-    hipLaunchKernelGGL(k_pair_grads<DP>, dim3(gx, gy, 2), dim3(PB), sm_cols > sm_rows ? sm_cols : sm_rows, st, P, C, z, g, v,
-                       lse_s, lse_k, ws);
-    hipLaunchKernelGGL(k_pair_finish, dim3(gx, d, 3), dim3(PB), 0, st, P, logMN, ws, lse_s, lse_k, lq, lqi, rz, cg, cv);
+    hipLaunchKernelGGL(k_pair_grads<DP>, dim3(gx * nm, gy, 2), dim3(PB), sm_cols > sm_rows ? sm_cols : sm_rows, st, P, C, z, g, v,
+                       lse_s, lse_k, ws, gx);
+    hipLaunchKernelGGL(k_pair_finish, dim3(gx * nm, d, 3), dim3(PB), 0, st, P, logMN, ws, lse_s, lse_k, lq, lqi, rz, cg, cv, gx);
     return hipGetLastError();
 }
 
@@ -433,18 +447,23 @@ __global__ __launch_bounds__(256) void k_pair_cols_wide(int n_rows, int n_cols, 
     }
 }
 
+// n_models packed problems of one shape: every pointer is the first model's, model m lives `mstride` floats further.
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
                            const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
-                           float* cg, float* cv, float* ws, hipStream_t st) {
+                           float* cg, float* cv, float* ws, int n_models, size_t mstride, hipStream_t st) {
     const float logMN = (float)log((double)C.global_batch * (double)C.dataset_size);   // np.log(M * N), nets.py:181
     if (d > 32) {
-        hipLaunchKernelGGL(k_pair_rows_wide, dim3((n_rows + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, logMN, z, g, v,
-                           lq, lqi, lse_s, lse_k, rz);
-        hipLaunchKernelGGL(k_pair_cols_wide, dim3((n_cols + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, z, g, v,
-                           lse_s, lse_k, cg, cv);
+        for (int m = 0; m < n_models; ++m) {
+            const size_t o = (size_t)m * mstride;
+            hipLaunchKernelGGL(k_pair_rows_wide, dim3((n_rows + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, logMN, z + o,
+                               g + o, v + o, lq + o, lqi + o, lse_s + o, lse_k + o, rz + o);
+            hipLaunchKernelGGL(k_pair_cols_wide, dim3((n_cols + 3) / 4), dim3(256), 0, st, n_rows, n_cols, d, C, z + o, g + o,
+                               v + o, lse_s + o, lse_k + o, cg + o, cv + o);
+        }
         return hipGetLastError();
     }
-    const PairGeom P = pair_geometry(n_rows, n_cols, d);
+    PairGeom P = pair_geometry(n_rows, n_cols, d);
+    P.n_models = n_models; P.mstride = mstride;
 #define PAIR_CASE(DP_) case DP_: return launch_sliced<DP_>(P, C, logMN, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, ws, st);
     switch (P.dp) {
         PAIR_CASE(4) PAIR_CASE(8) PAIR_CASE(12) PAIR_CASE(16) PAIR_CASE(20) PAIR_CASE(24) PAIR_CASE(28) PAIR_CASE(32)

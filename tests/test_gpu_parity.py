@@ -216,9 +216,11 @@ def test_pairwise_rectangular_matches_oracle(nr, nc, d):
         assert relmax(out[k].cpu().numpy(), r) < 5e-6, k
 
 
-def test_packed_models_equal_individual_runs():
-    """n_models=3 in one launch == three single-model launches (config-5 packing)."""
-    c = Case("ivae_plain_b70")
+@pytest.mark.parametrize("case", ["ivae_plain_b70", "cleanivae_lrelu_b70"])
+def test_packed_models_equal_individual_runs(case):
+    """n_models=3 in one launch == three single-model launches (config-5 packing); the pairwise case runs the
+    model-batched B x B x d kernels."""
+    c = Case(case)
     d = dev()
     names = c.spec.param_names()
     rng = np.random.RandomState(0)
