@@ -25,11 +25,11 @@
 #include "layout.h"
 #include "kernels.h"
 
-#define NT 256
+#define NR 256            // threads of a k_reduce block
 #define KCH 64            // contraction extent of a staged chunk
-#define NCH 64            // rows (output columns) of a staged chunk
 #define LDC 68            // chunk row stride (4 * odd)
-#define CHUNK (NCH * LDC)
+// Geometry of a workgroup of NW waves (4, 8 or 16): NT threads, chunks of NCH = 16 NW rows (output columns) x KCH
+#define GEOM(NW) constexpr int NT = 64 * (NW), NCH = 16 * (NW), CHUNK = NCH * LDC; (void)NT; (void)NCH; (void)CHUNK
 #define LOG2PI 1.8378770664093453f
 
 // Diagnostic build only (-DMF_PROF): s_memtime stamps of workgroup 0 / thread 0 go to a buffer of their own; no
@@ -108,7 +108,7 @@ struct BSrc {
 //   transposing kinds (WT, ROWS: contiguous along j), thread (w = tid >> 6, l = tid & 63), 16 scalar elements:
 //     j = (l & 7) + 8w + 32(e & 1), k = (l >> 3) + 8(e >> 1)  (8 consecutive j x 8 k per wave keep both the 32-B global
 //     segments and the LDS banks of the transposed store distinct); out-of-range elements read a clamped address.
-template <bool LOAD>
+template <bool LOAD, int NW>
 __device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const BSrc& S, int j0, int k0, float* wb) {
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));       // opaque: keeps the per-element addresses of every call site from being hoisted
@@ -126,14 +126,14 @@ __device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const B
             const int vo = ((j0 + jq) * S.ld + c0) * 4, vb = ((int)S.d2 + j0 + jq) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, e * 64 * S.ld, 0));
+                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, e * 16 * NW * S.ld, 0));
                 r[4 * e] = t[0]; r[4 * e + 1] = t[1]; r[4 * e + 2] = t[2]; r[4 * e + 3] = t[3];
-                if (isw) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vb, e * 64, 0));
+                if (isw) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vb, e * 16 * NW, 0));
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int j = j0 + jq + 16 * e;
+                const int j = j0 + jq + 4 * NW * e;
                 f32x4 o;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -147,12 +147,12 @@ __device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const B
                     }
                     o[i] = v;
                 }
-                *reinterpret_cast<f32x4*>(wb + (jq + 16 * e) * LDC + 4 * kq) = o;
+                *reinterpret_cast<f32x4*>(wb + (jq + 4 * NW * e) * LDC + 4 * kq) = o;
             }
         }
     } else if (S.kind == SRC_WT) {
         const int jl = (l & 7) + 8 * w, kl = l >> 3;
-        const int ja = j0 + jl, jb = ja + 32;
+        const int ja = j0 + jl, jb = ja + 8 * NW;
         const int oj[2] = {min(ja, S.J - 1), min(jb, S.J - 1)};
         const bool vj[2] = {ja < S.J, jb < S.J};
         float* dst = wb + jl * LDC + kl;
@@ -160,12 +160,12 @@ __device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const B
         for (int e = 0; e < 16; ++e) {
             const int k = k0 + kl + 8 * (e >> 1);
             if (LOAD) r[e] = p[min(k, S.K - 1) * S.ld + oj[e & 1]];
-            else dst[32 * (e & 1) * LDC + 8 * (e >> 1)] = (vj[e & 1] && k < S.K) ? r[e] : 0.f;
+            else dst[8 * NW * (e & 1) * LDC + 8 * (e >> 1)] = (vj[e & 1] && k < S.K) ? r[e] : 0.f;
         }
     } else if (S.kind == SRC_ROWS) {
         const int jl = (l & 7) + 8 * w, kl = l >> 3;
         const bool two = S.J > S.J1;
-        const int ja = j0 + jl, jb = ja + 32;
+        const int ja = j0 + jl, jb = ja + 8 * NW;
         // column offset inside a row of block a (stride ld) or block b (stride ld2, at p + d2)
         const bool inb[2] = {two && ja >= S.J1, two && jb >= S.J1};
         const long cj[2] = {inb[0] ? S.d2 + (min(ja, S.J - 1) - S.J1) : (long)min(ja, S.J1 - 1),
@@ -177,7 +177,7 @@ __device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const B
         for (int e = 0; e < 16; ++e) {
             const int k = k0 + kl + 8 * (e >> 1);
             if (LOAD) r[e] = p[cj[e & 1] + (long)(min(k, S.K - 1) * rs[e & 1])];
-            else dst[32 * (e & 1) * LDC + 8 * (e >> 1)] = k < S.K ? (vj[e & 1] == 1 ? r[e] : vj[e & 1] == 2 ? 1.f : 0.f) : 0.f;
+            else dst[8 * NW * (e & 1) * LDC + 8 * (e >> 1)] = k < S.K ? (vj[e & 1] == 1 ? r[e] : vj[e & 1] == 2 ? 1.f : 0.f) : 0.f;
         }
     }
 }
@@ -190,11 +190,13 @@ struct Stream {           // chunk pipeline state carried from one product to th
     int par;              // which one the next chunk goes to
     int n;                // diagnostic build: stamps written so far
 };
+template <int NW>
 __device__ __forceinline__ void chunk_load(Stream& St, const BSrc& S, int j0, int k0) {
-    if (S.kind != SRC_NONE) chunk_io<true>(St.r, St.rb, S, j0, k0, nullptr);
+    if (S.kind != SRC_NONE) chunk_io<true, NW>(St.r, St.rb, S, j0, k0, nullptr);
 }
+template <int NW>
 __device__ __forceinline__ void chunk_store(Stream& St, const BSrc& S, int j0, int k0, float* wb) {
-    chunk_io<false>(St.r, St.rb, S, j0, k0, wb);
+    chunk_io<false, NW>(St.r, St.rb, S, j0, k0, wb);
 }
 
 // out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RT (RT <= RTE row tiles), j < Jn, k < Kc.
@@ -205,10 +207,11 @@ __device__ __forceinline__ void chunk_store(Stream& St, const BSrc& S, int j0, i
 // epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0), fetched
 // BEFORE the contraction so that global operands of the epilogue (pre-activations of the dgrad mask) arrive under it.
 struct NoPre { __device__ __forceinline__ f32x4 operator()(int, int) const { return ZERO4; } };
-template <int RTE, class EPI, class PRE = NoPre>
+template <int RTE, int NW, class EPI, class PRE = NoPre>
 __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, int Jn, int Kc, const BSrc& next,
                                           Stream& St, EPI&& epi, PRE&& pre = PRE()) {
-    constexpr int WN = 4 / RTE, NTW = RTE;
+    GEOM(NW);
+    constexpr int WN = NW / RTE, NTW = RTE;
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, q = lane >> 4;
@@ -224,14 +227,14 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
             float* wb = St.wbuf + St.par * CHUNK;
             St.par ^= 1;
             MSTAMP(1);
-            chunk_store(St, S, j0, k0, wb);
+            chunk_store<NW>(St, S, j0, k0, wb);
             MSTAMP(2);
             __syncthreads();
             MSTAMP(3);
             // prefetch: next k chunk, else next column block, else the following product's first chunk
-            if (k0 + KCH < K16) chunk_load(St, S, j0, k0 + KCH);
-            else if (j0 + NCH < Jn) chunk_load(St, S, j0 + NCH, 0);
-            else chunk_load(St, next, 0, 0);
+            if (k0 + KCH < K16) chunk_load<NW>(St, S, j0, k0 + KCH);
+            else if (j0 + NCH < Jn) chunk_load<NW>(St, S, j0 + NCH, 0);
+            else chunk_load<NW>(St, next, 0, 0);
             MSTAMP(4);
             if (active) {
                 const float* ap = A + (16 * rt + c) * lda + k0 + 4 * q;
@@ -292,7 +295,7 @@ __device__ __forceinline__ BSrc src_w(const Layout& L, const MlpDesc& D, const f
 // One MLP forward.  `in` (LDS, stride ld_in) holds the layer-0 input with a constant-1 column after its Kin0
 // columns; `holey`: the input tile is [x | pad | u | 1] and W's columns skip the pad.  head(rt, col0, acc) receives
 // the output layer's tiles.  `next`: first streamed operand of whatever product follows this MLP.
-template <int RTE, class HEAD>
+template <int RTE, int NW, class HEAD>
 __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const MlpDesc& D, const float* in, int ld_in, int Kin0, bool holey,
                                         const BSrc& next, Stream& St, HEAD&& head) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
@@ -307,11 +310,11 @@ __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const 
         MSTAMP(7);
         const int N = D.dout[li];
         if (last) {
-            tile_gemm<RTE>(cur, ldc, RTE, S, N, Kc, nx, St, head);
+            tile_gemm<RTE, NW>(cur, ldc, RTE, S, N, Kc, nx, St, head);
         } else {
             float* dst = (li & 1) ? X.h1 : X.h0;
             float* preT = X.wsm + D.pre_off[li] + X.row0;
-            tile_gemm<RTE>(cur, ldc, RTE, S, N, Kc, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+            tile_gemm<RTE, NW>(cur, ldc, RTE, S, N, Kc, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                 const int n = col0 + c;
                 if (n < N) {
                     const int r0 = 16 * rt + 4 * q;
@@ -329,10 +332,11 @@ __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const 
 // Encoder / prior forward.  blockIdx.z picks the MLP: 0 = g, 1 = logv, 2 = logl; the three chains of a row tile
 // run as three concurrent workgroups (a third of the dependent-layer latency, three times the workgroups).
 // Writes g, v = exp(logv), l = exp(logl) rows to the workspace.
-template <int RTE>
-__global__ __launch_bounds__(NT) void k_fwd_enc(Layout L, const float* __restrict__ params, const float* __restrict__ x,
+template <int RTE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __restrict__ params, const float* __restrict__ x,
                                                 const float* __restrict__ u, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    GEOM(NW);
     const int TR = L.tr;
     float* wbuf = smem;
     float* xin = wbuf + 2 * CHUNK;          // [x | pad | u | 1 | 0..]
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(NT) void k_fwd_enc(Layout L, const float* __restric
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 0;
     MSTAMP(100);
-    chunk_load(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), 0, 0);
+    chunk_load<NW>(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), 0, 0);
 
     for (int i = 4 * tid; i < L.smem_enc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(xin + i) = ZERO4;
     __syncthreads();
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(NT) void k_fwd_enc(Layout L, const float* __restric
     FwdCtx X;
     X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = h0; X.h1 = h1;
     float* out = wsm + (m == IVAE_MLP_G ? L.ws.g : m == IVAE_MLP_LOGV ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
-    mlp_fwd<RTE>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
+    mlp_fwd<RTE, NW>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
                  [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                      const int n = col0 + c;
                      if (n < L.dl) {
@@ -415,7 +419,7 @@ __device__ __forceinline__ BSrc bwd_src(const Layout& L, const BwdCtx& X, const 
 // Backward of one MLP for a row tile.  On entry X.d[0] / X.dT hold dLoss/d(output) (rows >= nrows zero).  Writes
 // the tile's weight / bias gradient slab; when dx_out != null leaves dLoss/d(input) there (LDS, stride ld_dx).
 // Layer-0 input rows come from global memory: in_a (width na) followed by in_b (width nb).
-template <int RTE>
+template <int RTE, int NW>
 __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const MlpDesc& D, const float* in_a, int na, const float* in_b, int nb,
                                         float* dx_out, int ld_dx, const BSrc& next, Stream& St) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
@@ -437,7 +441,7 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                 const bool more = rc + 4 < NTl;
                 BSrc nx2 = nx;
                 if (more) nx2 = S;
-                tile_gemm<4>(X.dT + rc * 16 * L.ldr, L.ldr, min(4, NTl - rc), S, K + 1, X.TR, nx2, St,
+                tile_gemm<4, NW>(X.dT + rc * 16 * L.ldr, L.ldr, min(4, NTl - rc), S, K + 1, X.TR, nx2, St,
                           [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                               const int k = col0 + c;
 #pragma unroll
@@ -456,7 +460,7 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
             if (li > 0) {
                 float* dnx = cur ? X.d0 : X.d1;
                 const float* preT = X.wsm + D.pre_off[li - 1] + X.row0;
-                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
+                tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
                     const int k = col0 + c;
                     if (k < K) {
                         const int r0 = 16 * rt + 4 * q;
@@ -474,7 +478,7 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                 });
                 cur ^= 1;
             } else {
-                tile_gemm<RTE>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+                tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                     const int k = col0 + c;
                     if (k < K) {
 #pragma unroll
@@ -490,12 +494,13 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
 // backward (weight-gradient slab of f, dLoss/dz through the decoder -> workspace).  The decoder's backward needs
 // nothing from other rows, so ivae_elbo_fwd_bwd runs both bits in one launch; the encoder / prior head deltas,
 // which take the pairwise terms, are formed later by k_bwd_enc.
-template <int RTE>
-__global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
+template <int RTE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
                                             const float* __restrict__ x, const float* __restrict__ eps,
                                             float* __restrict__ z_out, float* __restrict__ ws, float* __restrict__ slabs,
                                             long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    GEOM(NW);
     const int TR = L.tr, lds = L.lds;
     const int ldt = max(L.ldh, L.ldd);
     float* wbuf = smem;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 0;
     MSTAMP(199);
-    chunk_load(St, (mode & 1) ? src_w(L, DF, P, 0, false) : bwd_first, 0, 0);
+    chunk_load<NW>(St, (mode & 1) ? src_w(L, DF, P, 0, false) : bwd_first, 0, 0);
     for (int i = 4 * tid; i < L.smem_dec / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(t0 + i) = ZERO4;
     __syncthreads();
 
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
         }
         FwdCtx X;
         X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = t0; X.h1 = t1;
-        mlp_fwd<RTE>(L, X, DF, sz, lds, L.dl, false, (mode & 2) ? bwd_first : src_none(), St,
+        mlp_fwd<RTE, NW>(L, X, DF, sz, lds, L.dl, false, (mode & 2) ? bwd_first : src_none(), St,
                      [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                          const int n = col0 + c;
                          if (n < L.dd) {
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
             t0[r * L.ldd + k] = v;
             dT[k * L.ldr + r] = v;
         }
-        mlp_bwd<RTE>(L, B, DF, zrows, L.dl, nullptr, 0, sdz, lds, src_none(), St);
+        mlp_bwd<RTE, NW>(L, B, DF, zrows, L.dl, nullptr, 0, sdz, lds, src_none(), St);
         MSTAMP(201);
         __syncthreads();
         for (int idx = tid; idx < nrows * L.dl; idx += NT) {
@@ -604,12 +609,13 @@ __global__ __launch_bounds__(NT) void k_dec(Layout L, IvaeCoef C, int mode, cons
 
 // Encoder / prior backward.  blockIdx.z picks the MLP: 0 = g, 1 = logv, 2 = logl (three concurrent workgroups per row
 // tile).  Forms the output-layer delta of its head (SURVEY.md §8 a-bwd; pairwise terms included) and runs the chain.
-template <int RTE>
-__global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const float* __restrict__ params,
+template <int RTE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const float* __restrict__ params,
                                                 const float* __restrict__ x, const float* __restrict__ u,
                                                 const float* __restrict__ eps, float* __restrict__ ws,
                                                 float* __restrict__ slabs, long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    GEOM(NW);
     const int TR = L.tr;
     float* wbuf = smem;
     float* dA = wbuf + 2 * CHUNK;
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const floa
 
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 1000;      // (diagnostic stamps of this kernel go to slots 1000..)
-    chunk_load(St, bwd_src(L, X, L.mlp[m], 0, in_a, na, in_b, nb), 0, 0);
+    chunk_load<NW>(St, bwd_src(L, X, L.mlp[m], 0, in_a, na, in_b, nb), 0, 0);
     for (int i = 4 * tid; i < L.smem_benc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dA + i) = ZERO4;
     __syncthreads();
     for (int idx = tid; idx < nrows * L.dl; idx += NT) {
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const floa
         dA[r * L.ldd + k] = dlt;
         dT[k * L.ldr + r] = dlt;
     }
-    mlp_bwd<RTE>(L, X, L.mlp[m], in_a, na, in_b, nb, nullptr, 0, src_none(), St);
+    mlp_bwd<RTE, NW>(L, X, L.mlp[m], in_a, na, in_b, nb, nullptr, 0, src_none(), St);
     MSTAMP(202);
 }
 
@@ -669,12 +675,12 @@ __global__ __launch_bounds__(NT) void k_bwd_enc(Layout L, IvaeCoef C, const floa
 // t = g, g+4, ... with four independent accumulators (loads in flight), then the partials are combined in a fixed
 // order, so the result does not depend on scheduling.
 #define RED_P 64
-__global__ __launch_bounds__(NT) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
+__global__ __launch_bounds__(NR) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
                                                float* __restrict__ grads, float* __restrict__ loss_out) {
     const int model = blockIdx.y;
     const float* wsm = ws + (size_t)model * L.ws.per_model;
     const int nblk_p = L.n_tiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;   // one tile: the kernels wrote grads directly
-    __shared__ float red[NT];
+    __shared__ float red[NR];
     if ((int)blockIdx.x < nblk_p) {
         const int p = min((int)blockIdx.x * RED_P + (int)(threadIdx.x & 63), L.n_params - 1);
         const int g = threadIdx.x >> 6;
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(NT) void k_reduce(Layout L, IvaeCoef C, const float
     }
     if (!loss_out) return;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < L.B; i += NT) {
+    for (int i = threadIdx.x; i < L.B; i += NR) {
         const float lpx = wsm[L.ws.lpx + i], lqc = wsm[L.ws.lqc + i], lp = wsm[L.ws.lp + i];
         float row;
         if (C.pairwise) {
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(NT) void k_reduce(Layout L, IvaeCoef C, const float
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
+    for (int s = NR / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
@@ -735,25 +741,26 @@ static hipError_t set_smem(const void* fn, int bytes, SmemCache& cache) {
     return e;
 }
 
-template <int RTE>
+template <int RTE, int NW>
 static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
                            const float* eps, float* z_out, float* ws, float* grads, hipStream_t st) {
     static SmemCache cur_enc = {}, cur_dec = {}, cur_benc = {};
+    constexpr int NT = 64 * NW;
     const int nz = L.M > 0 ? 3 : 2;
     // gradient slabs: per-tile partials in the workspace, or the caller's gradient buffer itself when a model is one tile
     float* slabs = L.n_tiles > 1 ? ws + L.ws_partial : grads;
     const long slab_stride = L.n_tiles > 1 ? (long)L.ws.per_model : (long)L.n_params;
     hipError_t e;
     if (what == 0) {            // encoder / prior forward
-        if ((e = set_smem((const void*)k_fwd_enc<RTE>, L.smem_enc, cur_enc)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fwd_enc<RTE>, dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_enc, st, L, params, x, u, ws);
+        if ((e = set_smem((const void*)k_fwd_enc<RTE, NW>, L.smem_enc, cur_enc)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_enc, st, L, params, x, u, ws);
     } else if (what <= 3) {     // decoder: mode = what
-        if ((e = set_smem((const void*)k_dec<RTE>, L.smem_dec, cur_dec)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_dec<RTE>, dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws,
+        if ((e = set_smem((const void*)k_dec<RTE, NW>, L.smem_dec, cur_dec)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_dec<RTE, NW>), dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws,
                            slabs, slab_stride);
     } else {                    // encoder / prior backward
-        if ((e = set_smem((const void*)k_bwd_enc<RTE>, L.smem_benc, cur_benc)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_bwd_enc<RTE>, dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws,
+        if ((e = set_smem((const void*)k_bwd_enc<RTE, NW>, L.smem_benc, cur_benc)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_bwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws,
                            slabs, slab_stride);
     }
     return hipGetLastError();
@@ -761,9 +768,21 @@ static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const f
 
 static hipError_t launch_phase(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
                                const float* eps, float* z_out, float* ws, float* grads, hipStream_t st) {
-    if (L.tr == 16) return launch_t<1>(L, C, what, params, x, u, eps, z_out, ws, grads, st);
-    if (L.tr == 32) return launch_t<2>(L, C, what, params, x, u, eps, z_out, ws, grads, st);
-    return launch_t<4>(L, C, what, params, x, u, eps, z_out, ws, grads, st);
+#define GO(RTE_, NW_) return launch_t<RTE_, NW_>(L, C, what, params, x, u, eps, z_out, ws, grads, st)
+    if (L.nw == 8) {
+        if (L.tr == 16) GO(1, 8);
+        if (L.tr == 32) GO(2, 8);
+        GO(4, 8);
+    }
+    if (L.nw == 16) {
+        if (L.tr == 16) GO(1, 16);
+        if (L.tr == 32) GO(2, 16);
+        GO(4, 16);
+    }
+    if (L.tr == 16) GO(1, 4);
+    if (L.tr == 32) GO(2, 4);
+    GO(4, 4);
+#undef GO
 }
 
 // grads_for_dec_bwd != null: also run the decoder's backward inside the decoder launch (the caller then passes
@@ -782,6 +801,6 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
     if ((e = launch_phase(L, C, 4, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     const int nblk_p = L.n_tiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
     if (nblk_p == 0 && !loss_out) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(NT), 0, st, L, C, ws, grads, loss_out);
+    hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(NR), 0, st, L, C, ws, grads, loss_out);
     return hipGetLastError();
 }

@@ -140,7 +140,15 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 #endif
 }
-__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ f32x2 ld2(const float* p) {
+#ifdef FT_ABL_NOLDS           // timing experiment only: operand registers left undefined instead of read from LDS
+    f32x2 r;
+    asm volatile("" : "=v"(r) : "v"(p));
+    return r;
+#else
+    return *reinterpret_cast<const f32x2*>(p);
+#endif
+}
 __device__ __forceinline__ void st2(float* p, float a, float b) {
 #ifdef FT_ABL_NOSTORE         // timing experiment only: results computed, (almost) never stored
     if (a != 1.2345e30f) return;

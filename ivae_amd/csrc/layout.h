@@ -36,6 +36,7 @@ struct Layout {
     int64_t ws_pair;     // scratch of the pairwise kernels for a (B, B, dl) problem
     // row tiling of k_fwd_enc / k_dec / k_bwd_enc (elbo_mfma.hip)
     int tr, n_tiles;     // rows per workgroup (16, 32 or 64), workgroups per model
+    int nw;              // waves per workgroup (4, 8 or 16): a streamed operand chunk holds 16 nw output columns
     int Bp;              // batch rounded up to 64: leading dimension of the feature-major pre-activations
     int uoff;            // column of u inside the [x | pad | u | 1] input tile (multiple of 4)
     int ldx, ldh, lds;   // LDS row strides (4 * odd floats): input tile, hidden tiles, latent-width tiles
@@ -44,16 +45,18 @@ struct Layout {
     int64_t ws_dz;       // (B, dl) dLoss/dz through the decoder (k_dec -> k_bwd_enc)
 };
 
-#define IVAE_CHUNK_FLOATS (64 * 68)      // one streamed operand chunk (elbo_mfma.hip)
+#define IVAE_CHUNK_FLOATS(nw) (16 * (nw) * 68)      // one streamed operand chunk (elbo_mfma.hip)
 #define IVAE_LDS_LIMIT (160 * 1024)
 
 static inline int ivae_up16(int x) { return (x + 15) & ~15; }
 static inline int ivae_ld4o(int x) { return (((x + 3) >> 2) | 1) << 2; }     // smallest 4*odd >= x
 
 static inline bool ivae_lds_over(const Layout& L);
-static inline void ivae_tile_geometry(Layout& L, int tr) {
+static inline void ivae_tile_geometry(Layout& L, int tr, int nw) {
     const int wide = L.maxh;
     L.tr = tr;
+    L.nw = nw;
+    const int chunk = IVAE_CHUNK_FLOATS(nw);
     L.ldx = ivae_ld4o(ivae_up16(L.uoff + L.M + 1));
     L.ldh = ivae_ld4o(ivae_up16(L.H + 1));
     L.lds = ivae_ld4o(ivae_up16(L.dl + 1));
@@ -62,9 +65,9 @@ static inline void ivae_tile_geometry(Layout& L, int tr) {
     L.ldr = tr + 4;
     // +64 floats: k-steps past a tile's last column read (finite) neighbours; the last tile needs room for that
     const int ldt = L.ldh > L.ldd ? L.ldh : L.ldd;
-    L.smem_enc = 4 * (2 * IVAE_CHUNK_FLOATS + tr * L.ldx + 2 * tr * L.ldh + 64);
-    L.smem_dec = 4 * (2 * IVAE_CHUNK_FLOATS + 2 * tr * ldt + L.nT * L.ldr + 2 * tr * L.lds + 64);
-    L.smem_benc = 4 * (2 * IVAE_CHUNK_FLOATS + 2 * tr * L.ldd + L.nT * L.ldr + 64);
+    L.smem_enc = 4 * (2 * chunk + tr * L.ldx + 2 * tr * L.ldh + 64);
+    L.smem_dec = 4 * (2 * chunk + 2 * tr * ldt + L.nT * L.ldr + 2 * tr * L.lds + 64);
+    L.smem_benc = 4 * (2 * chunk + 2 * tr * L.ldd + L.nT * L.ldr + 64);
 }
 
 static inline bool ivae_lds_over(const Layout& L) {
@@ -127,8 +130,23 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) tr = v;
     }
-    ivae_tile_geometry(L, tr);
-    while (tr > 16 && ivae_lds_over(L)) { tr >>= 1; ivae_tile_geometry(L, tr); }
+    // waves per workgroup: 4 when the launch fills the chip by itself (several workgroups share a CU and hide each
+    // other's latencies) or no product streams more than 64 output columns; otherwise a wider workgroup takes
+    // 128 / 256 columns per chunk, so that a short dependent chain of layers needs fewer chunk round trips
+    int jmax = L.H + 1;                                            // widest streamed extent over all products
+    if (L.dd + L.M + 1 > jmax) jmax = L.dd + L.M + 1;
+    if (L.dl + 1 > jmax) jmax = L.dl + 1;
+    int nw = 4;
+    if ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 64) nw = jmax > 128 ? 16 : 8;
+    if (const char* e = getenv("IVAE_AMD_WAVES")) {              // tuning knob: 4, 8 or 16
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) nw = v;
+    }
+    ivae_tile_geometry(L, tr, nw);
+    while (ivae_lds_over(L) && (nw > 4 || tr > 16)) {
+        if (nw > 4) nw >>= 1; else tr >>= 1;
+        ivae_tile_geometry(L, tr, nw);
+    }
     if (ivae_lds_over(L)) return IVAE_E_TOOLARGE;
     L.n_tiles = (L.B + tr - 1) / tr;
     L.ws_partial = take((int64_t)L.n_tiles * L.n_params);

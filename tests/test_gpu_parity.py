@@ -296,14 +296,16 @@ def test_bad_inputs_raise():
         ops.elbo_fwd_bwd(shape_of(c), ops.make_coef(global_batch=5), P, x.cpu(), u, eps, ops.Workspace())
 
 
+@pytest.mark.parametrize("waves", [4, 8, 16])
 @pytest.mark.parametrize("tile_rows", [16, 32, 64])
 @pytest.mark.parametrize("name", ["ivae_plain_b70", "cleanivae_cfg1", "cleanvae_btcvae_b200", "ivae_plain_cfg4s",
                                   "ivae_plain_l4_none", "ivae_plain_l1"])
-def test_every_row_tiling_matches_reference_fixture(name, tile_rows, monkeypatch):
-    """The generic kernels pick 16, 32 or 64 batch rows per workgroup from the launch geometry (each is its own
-    wave -> tile map); IVAE_AMD_TILE_ROWS pins the choice so that every variant meets the same 1e-5 bar on ragged
-    batches, H = 100 xtanh, 1- and 4-layer MLPs."""
+def test_every_row_tiling_matches_reference_fixture(name, tile_rows, waves, monkeypatch):
+    """The generic kernels pick 16, 32 or 64 batch rows and 4, 8 or 16 waves per workgroup from the launch geometry
+    (each pair is its own wave -> tile map and chunk width); IVAE_AMD_TILE_ROWS / IVAE_AMD_WAVES pin the choice so that
+    every variant meets the same 1e-5 bar on ragged batches, H = 100 xtanh, 1- and 4-layer MLPs."""
     monkeypatch.setenv("IVAE_AMD_TILE_ROWS", str(tile_rows))
+    monkeypatch.setenv("IVAE_AMD_WAVES", str(waves))
     c = Case(name)
     loss, z, grads, ws = run_case(c)
     assert abs(float(loss[0]) - c.loss()) <= TOL * abs(c.loss())
