@@ -13,7 +13,7 @@
 // A lane loads 4 consecutive k of its row as one ds_read_b128 and feeds them to 4 MFMAs; both operands use the same
 // k permutation, so sums are unchanged up to fp32 order.  The chunks are double-buffered in LDS and their global loads
 // are issued one chunk ahead into registers (also across layer boundaries), so the L2 latency of the weights hides
-// behind the previous chunk's MFMAs.  Hidden pre-activations go to the caller's workspace feature-major
+// behind the previous chunk's MFMAs.  Hidden activations and their derivatives go to the caller's workspace feature-major
 // ((H, Bp), Bp = batch rounded up to 64) so that the backward pass reads them as transposed operands directly.
 // Weight gradients are written as per-tile slabs and summed in a fixed order by k_reduce: results are bitwise
 // reproducible run to run (no float atomics).
@@ -58,21 +58,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int up16(int x) { return (x + 15) & ~15; }
 
-__device__ __forceinline__ float act_fwd(float p, int act, float slope) {
+// activation h = act(p) and its derivative d = act'(p) from ONE evaluation of the transcendental: the forward epilogue
+// stores both (feature-major, workspace), so the backward pass evaluates no tanh / exp at all
+__device__ __forceinline__ void act_both(float p, int act, float slope, float& h, float& d) {
     switch (act) {
-        case IVAE_ACT_LRELU: return p > 0.f ? p : p * slope;
-        case IVAE_ACT_XTANH: return tanhf(p) + slope * p;
-        case IVAE_ACT_SIGMOID: return 1.f / (1.f + expf(-p));
-        default: return p;
-    }
-}
-
-__device__ __forceinline__ float act_bwd(float p, int act, float slope) {
-    switch (act) {
-        case IVAE_ACT_LRELU: return p > 0.f ? 1.f : slope;
-        case IVAE_ACT_XTANH: { float t = tanhf(p); return 1.f - t * t + slope; }
-        case IVAE_ACT_SIGMOID: { float s = 1.f / (1.f + expf(-p)); return s * (1.f - s); }
-        default: return 1.f;
+        case IVAE_ACT_LRELU: h = p > 0.f ? p : p * slope; d = p > 0.f ? 1.f : slope; break;
+        case IVAE_ACT_XTANH: { const float t = tanhf(p); h = t + slope * p; d = 1.f - t * t + slope; break; }
+        case IVAE_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-p)); h = s; d = s * (1.f - s); break; }
+        default: h = p; d = 1.f;
     }
 }
 
@@ -82,7 +75,7 @@ __device__ __forceinline__ float act_bwd(float p, int act, float slope) {
 //            carry a constant-1 column at k = K.  k in [hole0, hole0 + hole) is padding (zero) and later k shift
 //            down by `hole` ([x | pad | u | 1] input tiles).
 //   SRC_WT   dgrad:    Bm[j][k] = W[k][j]   (W is (K, J) row-major at p, row stride ld)
-//   SRC_PRE  wgrad of a hidden layer:  Bm[j][k] = act(preT[j][k]) (pre-activations feature-major at p, row stride ld,
+//   SRC_PRE  wgrad of a hidden layer:  Bm[j][k] = actT[j][k] (hidden activations feature-major at p, row stride ld,
 //            k = batch row < K), Bm[J][k] = 1 (its result row is the bias gradient)
 //   SRC_ROWS wgrad of a first layer:   Bm[j][k] = in[k][j], in = [a | b] row-major blocks (a: J1 columns at p, row
 //            stride ld; b: J - J1 columns at p + d2, row stride ld2), Bm[J][k] = 1
@@ -95,7 +88,6 @@ struct BSrc {
     int J1, J, K;
     int ld, ld2;
     int hole0, hole;
-    int act; float slope;
     unsigned lim;                   // SRC_W / SRC_PRE: floats readable from p (range of the buffer descriptor)
 };
 
@@ -143,7 +135,7 @@ __device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const B
                         const bool ok = j < S.J && !(k >= S.hole0 && k < S.hole0 + S.hole);
                         v = (ok && cc < S.K) ? r[4 * e + i] : (ok && cc == S.K) ? rb[e] : 0.f;
                     } else {
-                        v = (k < S.K && j < S.J) ? act_fwd(r[4 * e + i], S.act, S.slope) : (k < S.K && j == S.J) ? 1.f : 0.f;
+                        v = (k < S.K && j < S.J) ? r[4 * e + i] : (k < S.K && j == S.J) ? 1.f : 0.f;
                     }
                     o[i] = v;
                 }
@@ -205,7 +197,7 @@ __device__ __forceinline__ void chunk_store(Stream& St, const BSrc& S, int j0, i
 // and k-steps beyond the real extents multiply zero-filled chunk rows / columns (the epilogue drops them).
 // On entry St.r holds chunk (0, 0) of S; on exit it holds chunk (0, 0) of `next` (if any).
 // epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0), fetched
-// BEFORE the contraction so that global operands of the epilogue (pre-activations of the dgrad mask) arrive under it.
+// BEFORE the contraction so that global operands of the epilogue (activation derivatives of the dgrad mask) arrive under it.
 struct NoPre { __device__ __forceinline__ f32x4 operator()(int, int) const { return ZERO4; } };
 template <int RTE, int NW, class EPI, class PRE = NoPre>
 __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, int Jn, int Kc, const BSrc& next,
@@ -313,14 +305,22 @@ __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const 
             tile_gemm<RTE, NW>(cur, ldc, RTE, S, N, Kc, nx, St, head);
         } else {
             float* dst = (li & 1) ? X.h1 : X.h0;
-            float* preT = X.wsm + D.pre_off[li] + X.row0;
+            float* actT = X.wsm + D.pre_off[li] + X.row0;
+            float* derT = X.wsm + D.der_off[li] + X.row0;
             tile_gemm<RTE, NW>(cur, ldc, RTE, S, N, Kc, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                 const int n = col0 + c;
                 if (n < N) {
                     const int r0 = 16 * rt + 4 * q;
-                    *reinterpret_cast<f32x4*>(preT + (size_t)n * L.Bp + r0) = acc;
+                    f32x4 hv, dv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[(r0 + r) * L.ldh + n] = act_fwd(acc[r], L.act, L.slope);
+                    for (int r = 0; r < 4; ++r) {
+                        float h, d;
+                        act_both(acc[r], L.act, L.slope, h, d);
+                        hv[r] = h; dv[r] = d;
+                        dst[(r0 + r) * L.ldh + n] = h;
+                    }
+                    *reinterpret_cast<f32x4*>(actT + (size_t)n * L.Bp + r0) = hv;
+                    *reinterpret_cast<f32x4*>(derT + (size_t)n * L.Bp + r0) = dv;
                 }
             });
             cur = dst;
@@ -408,7 +408,7 @@ __device__ __forceinline__ BSrc bwd_src(const Layout& L, const BwdCtx& X, const 
         S.kind = SRC_WT; S.p = X.P + D.w_off[li]; S.J1 = S.J = D.din[li]; S.K = D.dout[li]; S.ld = D.din[li];
     } else if (li > 0) {
         S.kind = SRC_PRE; S.p = X.wsm + D.pre_off[li - 1] + X.row0; S.J1 = S.J = D.din[li]; S.K = X.nrows; S.ld = L.Bp;
-        S.act = L.act; S.slope = L.slope; { const long lim = L.ws.per_model - (D.pre_off[li - 1] + X.row0); S.lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
+        { const long lim = L.ws.per_model - (D.pre_off[li - 1] + X.row0); S.lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
     } else {
         S.kind = SRC_ROWS; S.p = in_a; S.d2 = in_b ? in_b - in_a : 0L; S.J1 = na; S.J = na + nb; S.K = X.nrows;
         S.ld = na; S.ld2 = nb;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
             const float* dcur = cur ? X.d1 : X.d0;
             if (li > 0) {
                 float* dnx = cur ? X.d0 : X.d1;
-                const float* preT = X.wsm + D.pre_off[li - 1] + X.row0;
+                const float* derT = X.wsm + D.der_off[li - 1] + X.row0;
                 tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
                     const int k = col0 + c;
                     if (k < K) {
@@ -467,14 +467,14 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                         f32x4 o;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            o[r] = r0 + r < X.nrows ? acc[r] * act_bwd(pre[r], L.act, L.slope) : 0.f;
+                            o[r] = r0 + r < X.nrows ? acc[r] * pre[r] : 0.f;
                             dnx[(r0 + r) * L.ldd + k] = o[r];
                         }
                         *reinterpret_cast<f32x4*>(X.dT + k * L.ldr + r0) = o;
                     }
                 }, [&](int rt, int col0) {
                     const int k = min(col0 + c, K - 1);
-                    return *reinterpret_cast<const f32x4*>(preT + (size_t)k * L.Bp + 16 * rt + 4 * q);
+                    return *reinterpret_cast<const f32x4*>(derT + (size_t)k * L.Bp + 16 * rt + 4 * q);
                 });
                 cur ^= 1;
             } else {

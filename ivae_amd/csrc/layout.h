@@ -20,7 +20,8 @@ struct MlpDesc {
     int b_off[IVAE_MAX_LAYERS];
     int din[IVAE_MAX_LAYERS];
     int dout[IVAE_MAX_LAYERS];
-    int64_t pre_off[IVAE_MAX_LAYERS];  // workspace offset of hidden pre-activations (batch, hidden)
+    int64_t pre_off[IVAE_MAX_LAYERS];  // workspace offset of the hidden activations act(pre), feature-major (hidden, Bp)
+    int64_t der_off[IVAE_MAX_LAYERS];  // ... and of the activation derivatives act'(pre), same layout
 };
 
 struct Layout {
@@ -103,14 +104,14 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
         if (m == IVAE_MLP_LOGL) { D.in_dim = L.M; D.out_dim = L.dl; }
         else if (m == IVAE_MLP_F) { D.in_dim = L.dl; D.out_dim = L.dd; }
         else { D.in_dim = L.dd + L.M; D.out_dim = L.dl; }
-        for (int li = 0; li < IVAE_MAX_LAYERS; ++li) { D.w_off[li] = D.b_off[li] = D.din[li] = D.dout[li] = 0; D.pre_off[li] = 0; }
+        for (int li = 0; li < IVAE_MAX_LAYERS; ++li) { D.w_off[li] = D.b_off[li] = D.din[li] = D.dout[li] = 0; D.pre_off[li] = D.der_off[li] = 0; }
         if (!D.present) continue;
         for (int li = 0; li < L.L; ++li) {
             D.din[li] = li == 0 ? D.in_dim : L.H;
             D.dout[li] = li == L.L - 1 ? D.out_dim : L.H;
             D.w_off[li] = off; off += D.din[li] * D.dout[li];
             D.b_off[li] = off; off += D.dout[li];
-            if (li < L.L - 1) { D.pre_off[li] = wso; wso += (int64_t)L.Bp * L.H; }
+            if (li < L.L - 1) { D.pre_off[li] = wso; wso += (int64_t)L.Bp * L.H; D.der_off[li] = wso; wso += (int64_t)L.Bp * L.H; }
         }
     }
     L.n_params = off;
