@@ -391,22 +391,25 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
 // ------------------------------------------------------------------------------ backward
 struct BwdCtx {
     const float* P;
-    const float* wsm;
+    float* wsm;
     float* slab;
     int row0, nrows, TR;
     float* d0;             // delta tiles, row-major (TR, ldd)
     float* d1;
-    float* dT;             // delta transposed (n, ldr)
 };
 
-// Streamed operand of step s of an MLP's backward: s even = weight gradient of layer L-1-s/2, odd = its input gradient.
-__device__ __forceinline__ BSrc bwd_src(const Layout& L, const BwdCtx& X, const MlpDesc& D, int s, const float* in_a, int na,
-                                        const float* in_b, int nb) {
-    const int li = L.L - 1 - (s >> 1);
+// Streamed operand of the input-gradient product of layer li: W^T.
+__device__ __forceinline__ BSrc dgrad_src(const BwdCtx& X, const MlpDesc& D, int li) {
     BSrc S = src_none();
-    if (s & 1) {
-        S.kind = SRC_WT; S.p = X.P + D.w_off[li]; S.J1 = S.J = D.din[li]; S.K = D.dout[li]; S.ld = D.din[li];
-    } else if (li > 0) {
+    S.kind = SRC_WT; S.p = X.P + D.w_off[li]; S.J1 = S.J = D.din[li]; S.K = D.dout[li]; S.ld = D.din[li];
+    return S;
+}
+// Streamed operand of the weight-gradient product of layer li: the layer's input, transposed (hidden activations from
+// the workspace, or the layer-0 input rows in_a (width na) followed by in_b (width nb) from global memory).
+__device__ __forceinline__ BSrc wgrad_src(const Layout& L, const BwdCtx& X, const MlpDesc& D, int li, const float* in_a, int na,
+                                          const float* in_b, int nb) {
+    BSrc S = src_none();
+    if (li > 0) {
         S.kind = SRC_PRE; S.p = X.wsm + D.pre_off[li - 1] + X.row0; S.J1 = S.J = D.din[li]; S.K = X.nrows; S.ld = L.Bp;
         { const long lim = L.ws.per_model - (D.pre_off[li - 1] + X.row0); S.lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
     } else {
@@ -416,89 +419,133 @@ __device__ __forceinline__ BSrc bwd_src(const Layout& L, const BwdCtx& X, const 
     return S;
 }
 
-// Backward of one MLP for a row tile.  On entry X.d[0] / X.dT hold dLoss/d(output) (rows >= nrows zero).  Writes
-// the tile's weight / bias gradient slab; when dx_out != null leaves dLoss/d(input) there (LDS, stride ld_dx).
-// Layer-0 input rows come from global memory: in_a (width na) followed by in_b (width nb).
+// Input-gradient chain of one MLP for a row tile.  On entry X.d0 holds dLoss/d(output) (rows >= nrows zero) and the
+// caller has stored it feature-major at D.dlt_off[L-1].  Every hidden layer's delta goes to the workspace feature-major
+// (D.dlt_off[li], (dout, Bp)): the weight gradients -- which nothing in this chain waits for -- are formed from those by
+// k_wgrad, one workgroup per (row tile, layer), after the chains.  When dx_out != null the gradient with respect to the
+// MLP's input is left there (LDS, stride ld_dx).
 template <int RTE, int NW>
-__device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const MlpDesc& D, const float* in_a, int na, const float* in_b, int nb,
-                                        float* dx_out, int ld_dx, const BSrc& next, Stream& St) {
+__device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const MlpDesc& D, float* dx_out, int ld_dx, const BSrc& next,
+                                        Stream& St) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int n_steps = 2 * L.L - (dx_out ? 0 : 1);
+    const int n_prod = dx_out ? L.L : L.L - 1;
     int cur = 0;
-    for (int s = 0; s < n_steps; ++s) {
-        const int li = L.L - 1 - (s >> 1);
+    for (int t = 0; t < n_prod; ++t) {
+        const int li = L.L - 1 - t;
         const int N = D.dout[li], K = D.din[li];
-        const BSrc S = bwd_src(L, X, D, s, in_a, na, in_b, nb);
+        const BSrc S = dgrad_src(X, D, li);
         BSrc nx = next;
-        if (s + 1 < n_steps) nx = bwd_src(L, X, D, s + 1, in_a, na, in_b, nb);
+        if (t + 1 < n_prod) nx = dgrad_src(X, D, li - 1);
         MSTAMP(7);
-        if (!(s & 1)) {
-            // weight gradient dW[n][k] = sum_r delta[r][n] * in[r][k]; column K of the result is the bias gradient
-            float* gW = X.slab + D.w_off[li];
-            float* gB = X.slab + D.b_off[li];
-            const int NTl = (N + 15) >> 4;
-            for (int rc = 0; rc < NTl; rc += 4) {
-                const bool more = rc + 4 < NTl;
-                BSrc nx2 = nx;
-                if (more) nx2 = S;
-                tile_gemm<4, NW>(X.dT + rc * 16 * L.ldr, L.ldr, min(4, NTl - rc), S, K + 1, X.TR, nx2, St,
-                          [&](int rt, int col0, const f32x4& acc, const f32x4&) {
-                              const int k = col0 + c;
+        // dX[r][k] = sum_n delta[r][n] * W[n][k]  (times act'(pre) for a hidden input)
+        const float* dcur = cur ? X.d1 : X.d0;
+        if (li > 0) {
+            float* dnx = cur ? X.d0 : X.d1;
+            const float* derT = X.wsm + D.der_off[li - 1] + X.row0;
+            float* dltT = X.wsm + D.dlt_off[li - 1] + X.row0;
+            tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
+                const int k = col0 + c;
+                if (k < K) {
+                    const int r0 = 16 * rt + 4 * q;
+                    f32x4 o;
 #pragma unroll
-                              for (int r = 0; r < 4; ++r) {
-                                  const int n = 16 * (rc + rt) + 4 * q + r;
-                                  if (n < N) {
-                                      if (k < K) gW[(size_t)n * K + k] = acc[r];
-                                      else if (k == K) gB[n] = acc[r];
-                                  }
-                              }
-                          });
-            }
+                    for (int r = 0; r < 4; ++r) {
+                        o[r] = r0 + r < X.nrows ? acc[r] * pre[r] : 0.f;
+                        dnx[(r0 + r) * L.ldd + k] = o[r];
+                    }
+                    *reinterpret_cast<f32x4*>(dltT + (size_t)k * L.Bp + r0) = o;
+                }
+            }, [&](int rt, int col0) {
+                const int k = min(col0 + c, K - 1);
+                return *reinterpret_cast<const f32x4*>(derT + (size_t)k * L.Bp + 16 * rt + 4 * q);
+            });
+            cur ^= 1;
         } else {
-            // input gradient dX[r][k] = sum_n delta[r][n] * W[n][k]  (times act'(pre) for a hidden input)
-            const float* dcur = cur ? X.d1 : X.d0;
-            if (li > 0) {
-                float* dnx = cur ? X.d0 : X.d1;
-                const float* derT = X.wsm + D.der_off[li - 1] + X.row0;
-                tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
-                    const int k = col0 + c;
-                    if (k < K) {
-                        const int r0 = 16 * rt + 4 * q;
-                        f32x4 o;
+            tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+                const int k = col0 + c;
+                if (k < K) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            o[r] = r0 + r < X.nrows ? acc[r] * pre[r] : 0.f;
-                            dnx[(r0 + r) * L.ldd + k] = o[r];
-                        }
-                        *reinterpret_cast<f32x4*>(X.dT + k * L.ldr + r0) = o;
-                    }
-                }, [&](int rt, int col0) {
-                    const int k = min(col0 + c, K - 1);
-                    return *reinterpret_cast<const f32x4*>(derT + (size_t)k * L.Bp + 16 * rt + 4 * q);
-                });
-                cur ^= 1;
-            } else {
-                tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
-                    const int k = col0 + c;
-                    if (k < K) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) dx_out[(16 * rt + 4 * q + r) * ld_dx + k] = acc[r];
-                    }
-                });
-            }
+                    for (int r = 0; r < 4; ++r) dx_out[(16 * rt + 4 * q + r) * ld_dx + k] = acc[r];
+                }
+            });
         }
     }
 }
 
+// Weight / bias gradient of ONE layer of one MLP for a row tile: dW[n][k] = sum_r delta[r][n] * in[r][k], column K of
+// the result is the bias gradient.  blockIdx.z = mlp * L + layer (mlp order f, g, logv, logl).  delta^T comes from the
+// workspace (written by k_dec / k_bwd_enc), the layer input streams through LDS as in every other product; the result
+// goes to the tile's gradient slab.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_wgrad(Layout L, const float* __restrict__ params, const float* __restrict__ x,
+                                                   const float* __restrict__ u, float* __restrict__ ws,
+                                                   float* __restrict__ slabs, long slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    GEOM(NW);
+    const int TR = L.tr;
+    float* wbuf = smem;
+    float* dT = wbuf + 2 * CHUNK;           // delta transposed (n, ldr)
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
+    const int mi = blockIdx.z / L.L, li = blockIdx.z - mi * L.L;
+    const int m = mi == 0 ? IVAE_MLP_F : mi == 1 ? IVAE_MLP_G : mi == 2 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL;
+    const MlpDesc& D = L.mlp[m];
+    float* wsm = ws + (size_t)model * L.ws.per_model;
+    const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
+    const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
+    const float* zrows = wsm + L.ws.z + (size_t)row0 * L.dl;
+
+    BwdCtx X;
+    X.P = params + (size_t)model * L.n_params; X.wsm = wsm;
+    X.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.n_params;
+    X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = X.d1 = nullptr;
+    const float* in_a = m == IVAE_MLP_F ? zrows : m == IVAE_MLP_LOGL ? um : xm;
+    const int na = m == IVAE_MLP_F ? L.dl : m == IVAE_MLP_LOGL ? L.M : L.dd;
+    const float* in_b = (m == IVAE_MLP_G || m == IVAE_MLP_LOGV) ? um : nullptr;
+    const int nb = in_b ? L.M : 0;
+    const int N = D.dout[li], K = D.din[li];
+    const BSrc S = wgrad_src(L, X, D, li, in_a, na, in_b, nb);
+
+    Stream St;
+    St.wbuf = wbuf; St.par = 0; St.n = 1500;      // (diagnostic stamps of this kernel go to slots 1500..)
+    chunk_load<NW>(St, S, 0, 0);
+    for (int i = 4 * tid; i < L.smem_wg / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dT + i) = ZERO4;
+    __syncthreads();
+    const float* dlt = wsm + D.dlt_off[li] + row0;
+    for (int idx = tid; idx < N * TR; idx += NT) {
+        const int n = idx / TR, r = idx - n * TR;
+        if (r < nrows) dT[n * L.ldr + r] = dlt[(size_t)n * L.Bp + r];
+    }
+    // (the first tile_gemm's barrier orders these writes before any operand read)
+    float* gW = X.slab + D.w_off[li];
+    float* gB = X.slab + D.b_off[li];
+    const int NTl = (N + 15) >> 4;
+    for (int rc = 0; rc < NTl; rc += 4) {
+        BSrc nx = src_none();
+        if (rc + 4 < NTl) nx = S;
+        tile_gemm<4, NW>(dT + rc * 16 * L.ldr, L.ldr, min(4, NTl - rc), S, K + 1, TR, nx, St,
+                         [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+                             const int k = col0 + c;
+#pragma unroll
+                             for (int r = 0; r < 4; ++r) {
+                                 const int n = 16 * (rc + rt) + 4 * q + r;
+                                 if (n < N) {
+                                     if (k < K) gW[(size_t)n * K + k] = acc[r];
+                                     else if (k == K) gB[n] = acc[r];
+                                 }
+                             }
+                         });
+    }
+}
+
 // Decoder kernel.  mode bit 0: reparameterisation, decoder forward, the three per-row log-densities; bit 1: decoder
-// backward (weight-gradient slab of f, dLoss/dz through the decoder -> workspace).  The decoder's backward needs
+// input-gradient chain (layer deltas of f and dLoss/dz through the decoder -> workspace).  The decoder's backward needs
 // nothing from other rows, so ivae_elbo_fwd_bwd runs both bits in one launch; the encoder / prior head deltas,
 // which take the pairwise terms, are formed later by k_bwd_enc.
 template <int RTE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
                                             const float* __restrict__ x, const float* __restrict__ eps,
-                                            float* __restrict__ z_out, float* __restrict__ ws, float* __restrict__ slabs,
-                                            long slab_stride) {
+                                            float* __restrict__ z_out, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GEOM(NW);
     const int TR = L.tr, lds = L.lds;
@@ -506,8 +553,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     float* wbuf = smem;
     float* t0 = wbuf + 2 * CHUNK;           // hidden tiles (forward) / delta tiles (backward)
     float* t1 = t0 + TR * ldt;
-    float* dT = t1 + TR * ldt;
-    float* sz = dT + L.nT * L.ldr;          // z with its constant-1 column
+    float* sz = t1 + TR * ldt;              // z with its constant-1 column
     float* sdz = sz + TR * lds;
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
@@ -516,13 +562,12 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
     const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
     float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
-    const float* zrows = wsm + L.ws.z + (size_t)row0 * L.dl;
     const MlpDesc& DF = L.mlp[IVAE_MLP_F];
 
     BwdCtx B;
-    B.P = P; B.wsm = wsm; B.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.n_params;
-    B.row0 = row0; B.nrows = nrows; B.TR = TR; B.d0 = t0; B.d1 = t1; B.dT = dT;
-    const BSrc bwd_first = bwd_src(L, B, DF, 0, zrows, L.dl, nullptr, 0);
+    B.P = P; B.wsm = wsm; B.slab = nullptr;
+    B.row0 = row0; B.nrows = nrows; B.TR = TR; B.d0 = t0; B.d1 = t1;
+    const BSrc bwd_first = dgrad_src(B, DF, L.L - 1);
 
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 0;
@@ -590,14 +635,15 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     if (mode & 2) {
         // dLoss/df = -a*w*(x-f)/var, all TR rows (zero beyond the batch): the tiles may hold forward activations
         const float w = 1.f / (float)C.global_batch;
+        float* dltF = wsm + DF.dlt_off[L.L - 1] + row0;
         __syncthreads();
         for (int idx = tid; idx < TR * L.dd; idx += NT) {
             const int r = idx / L.dd, k = idx - r * L.dd;
             const float v = r < nrows ? -C.a * w * (xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k]) / C.decoder_var : 0.f;
             t0[r * L.ldd + k] = v;
-            dT[k * L.ldr + r] = v;
+            dltF[(size_t)k * L.Bp + r] = v;
         }
-        mlp_bwd<RTE, NW>(L, B, DF, zrows, L.dl, nullptr, 0, sdz, lds, src_none(), St);
+        mlp_bwd<RTE, NW>(L, B, DF, sdz, lds, src_none(), St);
         MSTAMP(201);
         __syncthreads();
         for (int idx = tid; idx < nrows * L.dl; idx += NT) {
@@ -608,42 +654,35 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
 }
 
 // Encoder / prior backward.  blockIdx.z picks the MLP: 0 = g, 1 = logv, 2 = logl (three concurrent workgroups per row
-// tile).  Forms the output-layer delta of its head (SURVEY.md §8 a-bwd; pairwise terms included) and runs the chain.
+// tile).  Forms the output-layer delta of its head (SURVEY.md §8 a-bwd; pairwise terms included) and runs the
+// input-gradient chain; the deltas go to the workspace for k_wgrad.
 template <int RTE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const float* __restrict__ params,
                                                 const float* __restrict__ x, const float* __restrict__ u,
-                                                const float* __restrict__ eps, float* __restrict__ ws,
-                                                float* __restrict__ slabs, long slab_stride) {
+                                                const float* __restrict__ eps, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GEOM(NW);
     const int TR = L.tr;
     float* wbuf = smem;
     float* dA = wbuf + 2 * CHUNK;
     float* dB = dA + TR * L.ldd;
-    float* dT = dB + TR * L.ldd;
     const int tid = threadIdx.x;
     const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
     const int mi = blockIdx.z;
     const int m = mi == 0 ? IVAE_MLP_G : mi == 1 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL;
     const float* P = params + (size_t)model * L.n_params;
     float* wsm = ws + (size_t)model * L.ws.per_model;
-    const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
-    const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
     const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
     const float w = 1.f / (float)C.global_batch;
-    const bool pri = m == IVAE_MLP_LOGL;
 
     BwdCtx X;
-    X.P = P; X.wsm = wsm; X.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.n_params;
-    X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = dA; X.d1 = dB; X.dT = dT;
-    const float* in_a = pri ? um : xm;
-    const int na = pri ? L.M : L.dd;
-    const float* in_b = pri ? nullptr : um;
-    const int nb = pri ? 0 : L.M;
+    X.P = P; X.wsm = wsm; X.slab = nullptr;
+    X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = dA; X.d1 = dB;
+    float* dltT = wsm + L.mlp[m].dlt_off[L.L - 1] + row0;
 
     Stream St;
     St.wbuf = wbuf; St.par = 0; St.n = 1000;      // (diagnostic stamps of this kernel go to slots 1000..)
-    chunk_load<NW>(St, bwd_src(L, X, L.mlp[m], 0, in_a, na, in_b, nb), 0, 0);
+    chunk_load<NW>(St, L.L > 1 ? dgrad_src(X, L.mlp[m], L.L - 1) : src_none(), 0, 0);
     for (int i = 4 * tid; i < L.smem_benc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dA + i) = ZERO4;
     __syncthreads();
     for (int idx = tid; idx < nrows * L.dl; idx += NT) {
@@ -665,9 +704,9 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
             dlt = w * C.d * 0.5f * (1.f - zz * zz / ll);
         }
         dA[r * L.ldd + k] = dlt;
-        dT[k * L.ldr + r] = dlt;
+        dltT[(size_t)k * L.Bp + r] = dlt;
     }
-    mlp_bwd<RTE, NW>(L, X, L.mlp[m], in_a, na, in_b, nb, nullptr, 0, src_none(), St);
+    mlp_bwd<RTE, NW>(L, X, L.mlp[m], nullptr, 0, src_none(), St);
     MSTAMP(202);
 }
 
@@ -744,7 +783,7 @@ static hipError_t set_smem(const void* fn, int bytes, SmemCache& cache) {
 template <int RTE, int NW>
 static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
                            const float* eps, float* z_out, float* ws, float* grads, hipStream_t st) {
-    static SmemCache cur_enc = {}, cur_dec = {}, cur_benc = {};
+    static SmemCache cur_enc = {}, cur_dec = {}, cur_benc = {}, cur_wg = {};
     constexpr int NT = 64 * NW;
     const int nz = L.M > 0 ? 3 : 2;
     // gradient slabs: per-tile partials in the workspace, or the caller's gradient buffer itself when a model is one tile
@@ -756,12 +795,14 @@ static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const f
         hipLaunchKernelGGL((k_fwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_enc, st, L, params, x, u, ws);
     } else if (what <= 3) {     // decoder: mode = what
         if ((e = set_smem((const void*)k_dec<RTE, NW>, L.smem_dec, cur_dec)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_dec<RTE, NW>), dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws,
+        hipLaunchKernelGGL((k_dec<RTE, NW>), dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws);
+    } else if (what == 5) {     // weight gradients of every layer of every MLP
+        if ((e = set_smem((const void*)k_wgrad<NW>, L.smem_wg, cur_wg)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_wgrad<NW>), dim3(L.n_tiles, L.n_models, (nz + 1) * L.L), dim3(NT), L.smem_wg, st, L, params, x, u, ws,
                            slabs, slab_stride);
-    } else {                    // encoder / prior backward
+    } else {                    // encoder / prior input-gradient chains
         if ((e = set_smem((const void*)k_bwd_enc<RTE, NW>, L.smem_benc, cur_benc)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws,
-                           slabs, slab_stride);
+        hipLaunchKernelGGL((k_bwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws);
     }
     return hipGetLastError();
 }
@@ -799,6 +840,7 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
     hipError_t e;
     if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     if ((e = launch_phase(L, C, 4, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
+    if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     const int nblk_p = L.n_tiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
     if (nblk_p == 0 && !loss_out) return hipSuccess;
     hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(NR), 0, st, L, C, ws, grads, loss_out);

@@ -22,6 +22,7 @@ struct MlpDesc {
     int dout[IVAE_MAX_LAYERS];
     int64_t pre_off[IVAE_MAX_LAYERS];  // workspace offset of the hidden activations act(pre), feature-major (hidden, Bp)
     int64_t der_off[IVAE_MAX_LAYERS];  // ... and of the activation derivatives act'(pre), same layout
+    int64_t dlt_off[IVAE_MAX_LAYERS];  // dLoss/d(pre-activation output) of every layer, feature-major (dout, Bp)
 };
 
 struct Layout {
@@ -42,7 +43,7 @@ struct Layout {
     int uoff;            // column of u inside the [x | pad | u | 1] input tile (multiple of 4)
     int ldx, ldh, lds;   // LDS row strides (4 * odd floats): input tile, hidden tiles, latent-width tiles
     int ldd, ldr, nT;    // delta tiles (row-major stride), transposed delta (stride, rows)
-    int smem_enc, smem_dec, smem_benc;   // dynamic LDS bytes of k_fwd_enc, k_dec, k_bwd_enc
+    int smem_enc, smem_dec, smem_benc, smem_wg;   // dynamic LDS bytes of k_fwd_enc, k_dec, k_bwd_enc, k_wgrad
     int64_t ws_dz;       // (B, dl) dLoss/dz through the decoder (k_dec -> k_bwd_enc)
 };
 
@@ -67,12 +68,13 @@ static inline void ivae_tile_geometry(Layout& L, int tr, int nw) {
     // +64 floats: k-steps past a tile's last column read (finite) neighbours; the last tile needs room for that
     const int ldt = L.ldh > L.ldd ? L.ldh : L.ldd;
     L.smem_enc = 4 * (2 * chunk + tr * L.ldx + 2 * tr * L.ldh + 64);
-    L.smem_dec = 4 * (2 * chunk + 2 * tr * ldt + L.nT * L.ldr + 2 * tr * L.lds + 64);
-    L.smem_benc = 4 * (2 * chunk + 2 * tr * L.ldd + L.nT * L.ldr + 64);
+    L.smem_dec = 4 * (2 * chunk + 2 * tr * ldt + 2 * tr * L.lds + 64);
+    L.smem_benc = 4 * (2 * chunk + 2 * tr * L.ldd + 64);
+    L.smem_wg = 4 * (2 * chunk + L.nT * L.ldr + 64);
 }
 
 static inline bool ivae_lds_over(const Layout& L) {
-    return L.smem_enc > IVAE_LDS_LIMIT || L.smem_dec > IVAE_LDS_LIMIT || L.smem_benc > IVAE_LDS_LIMIT;
+    return L.smem_enc > IVAE_LDS_LIMIT || L.smem_dec > IVAE_LDS_LIMIT || L.smem_benc > IVAE_LDS_LIMIT || L.smem_wg > IVAE_LDS_LIMIT;
 }
 
 static inline int ivae_check_dims(const IvaeDims* d) {
@@ -104,7 +106,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
         if (m == IVAE_MLP_LOGL) { D.in_dim = L.M; D.out_dim = L.dl; }
         else if (m == IVAE_MLP_F) { D.in_dim = L.dl; D.out_dim = L.dd; }
         else { D.in_dim = L.dd + L.M; D.out_dim = L.dl; }
-        for (int li = 0; li < IVAE_MAX_LAYERS; ++li) { D.w_off[li] = D.b_off[li] = D.din[li] = D.dout[li] = 0; D.pre_off[li] = D.der_off[li] = 0; }
+        for (int li = 0; li < IVAE_MAX_LAYERS; ++li) { D.w_off[li] = D.b_off[li] = D.din[li] = D.dout[li] = 0; D.pre_off[li] = D.der_off[li] = D.dlt_off[li] = 0; }
         if (!D.present) continue;
         for (int li = 0; li < L.L; ++li) {
             D.din[li] = li == 0 ? D.in_dim : L.H;
@@ -112,6 +114,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
             D.w_off[li] = off; off += D.din[li] * D.dout[li];
             D.b_off[li] = off; off += D.dout[li];
             if (li < L.L - 1) { D.pre_off[li] = wso; wso += (int64_t)L.Bp * L.H; D.der_off[li] = wso; wso += (int64_t)L.Bp * L.H; }
+            D.dlt_off[li] = wso; wso += (int64_t)L.Bp * D.dout[li];
         }
     }
     L.n_params = off;
