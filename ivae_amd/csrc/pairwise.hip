@@ -307,6 +307,183 @@ static hipError_t launch_sliced(const PairGeom& P, const IvaeCoef& C, float logM
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ small problems: one workgroup, one launch
+// n_rows, n_cols <= 64 and d <= 12 (every yaml config of the reference: batch 64, d = 5 or 10): the four stages above run
+// inside ONE workgroup per model, so a training step spends one launch on the pairwise terms instead of four.
+// Thread = (lane l, wave p): in the row role lane l owns row l and wave p walks columns [16p, 16p + 16); in the column
+// role lane l owns column l and wave p walks rows [16p, 16p + 16).  The four waves' partial statistics / sums meet in
+// LDS and are merged in a fixed order (deterministic), with the same arithmetic as the sliced kernels.
+#define PSM 64                     // rows / columns of a small problem
+#define PSQ 16                     // per wave
+template <int DP>
+__global__ __launch_bounds__(PB) void k_pair_small(int n_rows, int n_cols, int d, IvaeCoef C, float logMN,
+                                                   const float* __restrict__ z, const float* __restrict__ g,
+                                                   const float* __restrict__ v, float* __restrict__ lq,
+                                                   float* __restrict__ lqi, float* __restrict__ lse_s,
+                                                   float* __restrict__ lse_k, float* __restrict__ rz,
+                                                   float* __restrict__ cg, float* __restrict__ cv, size_t mstride) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const size_t mo = (size_t)blockIdx.x * mstride;
+    z += mo; g += mo; v += mo; lq += mo; lqi += mo; lse_s += mo; lse_k += mo; rz += mo; cg += mo; cv += mo;
+    float* G = sm;                          // (PSM, DP) column constants
+    float* W2 = G + PSM * DP;
+    float* A2 = W2 + PSM * DP;
+    float* Z = A2 + PSM * DP;               // (PSM, DP) rows
+    float* LK = Z + PSM * DP;               // (PSM, DP) lse_k (natural log)
+    float* LS = LK + PSM * DP;              // (PSM) lse_s
+    float* part = LS + PSM;                 // stage 1-2: pm, ps (4, DP + 1, PSM) each; stage 3-4: rz, cg, cv partials (4, DP, PSM) each
+    float* pm = part;
+    float* ps = pm + 4 * (DP + 1) * PSM;
+    float* pr = part;
+    float* pg = pr + 4 * DP * PSM;
+    float* pv = pg + 4 * DP * PSM;
+    const int tid = threadIdx.x, l = tid & 63, p = tid >> 6;
+    const float cP = C.b - C.c, cQ = C.c - C.d;
+
+    stage_cols<DP>(g, v, 0, n_cols, d, G, W2, A2);
+    for (int e = tid; e < n_rows * DP; e += PB) {
+        const int i = e / DP, k = e - i * DP;
+        Z[e] = k < d ? z[(size_t)i * d + k] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- stage 1: per-wave statistics of row l over the wave's columns
+    const int ic = min(l, n_rows - 1);
+    const int j0 = PSQ * p, j1 = min(j0 + PSQ, n_cols);
+    float zi[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) zi[k] = Z[ic * DP + k];
+    {
+        float m[DP], s[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) { m[k] = NEG_BIG; s[k] = 0.f; }
+        float mS = NEG_BIG, sS = 0.f;
+        for (int j = j0; j < j1; ++j) {
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float dq = zi[k] - G[j * DP + k];
+                const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
+                m[k] = fmaxf(m[k], t);
+                S += t;
+            }
+            mS = fmaxf(mS, S);
+        }
+        for (int j = j0; j < j1; ++j) {
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float dq = zi[k] - G[j * DP + k];
+                const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
+                s[k] += fexp2(t - m[k]);
+                S += t;
+            }
+            sS += fexp2(S - mS);
+        }
+#pragma unroll
+        for (int k = 0; k < DP; ++k) { pm[(p * (DP + 1) + k) * PSM + l] = m[k]; ps[(p * (DP + 1) + k) * PSM + l] = s[k]; }
+        pm[(p * (DP + 1) + DP) * PSM + l] = mS;
+        ps[(p * (DP + 1) + DP) * PSM + l] = sS;
+    }
+    __syncthreads();
+
+    // ---- stage 2: merge the four waves (log2 units in, natural-log LSE out); plane DP is the sum-over-k statistic
+    for (int e = tid; e < (d + 1) * PSM; e += PB) {
+        const int kk = e / PSM, i = e - kk * PSM;
+        const int k = kk == d ? DP : kk;
+        float M = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, pm[(w * (DP + 1) + k) * PSM + i]);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += ps[(w * (DP + 1) + k) * PSM + i] * exp2f(pm[(w * (DP + 1) + k) * PSM + i] - M);
+        const float lse = M * LN2 + logf(sum);
+        if (kk == d) { LS[i] = lse; if (i < n_rows) lse_s[i] = lse; }
+        else { LK[i * DP + kk] = lse; if (i < n_rows) lse_k[(size_t)i * d + kk] = lse; }
+    }
+    __syncthreads();
+    if (tid < n_rows) {
+        float acc = 0.f;
+        for (int kk = 0; kk < d; ++kk) acc += LK[tid * DP + kk] - logMN;
+        lq[tid] = LS[tid] - logMN;
+        lqi[tid] = acc;
+    }
+
+    // ---- stage 3a: row role -> rz partials of the wave's columns
+    {
+        float lk[DP], acc[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) { lk[k] = k < d ? LK[ic * DP + k] * LOG2E : 0.f; acc[k] = 0.f; }
+        const float LSi = LS[ic] * LOG2E;
+        for (int j = j0; j < j1; ++j) {
+            float tt[DP], rr[DP];
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float dq = zi[k] - G[j * DP + k];
+                rr[k] = dq * W2[j * DP + k];
+                tt[k] = A2[j * DP + k] - dq * rr[k];
+                S += tt[k];
+            }
+            const float Pij = cP * fexp2(S - LSi);
+#pragma unroll
+            for (int k = 0; k < DP; ++k) acc[k] -= (Pij + cQ * fexp2(tt[k] - lk[k])) * rr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < DP; ++k) pr[(p * DP + k) * PSM + l] = acc[k] * (2.f * LN2);
+    }
+    // ---- stage 3b: column role (lane = column l) -> cg, cv partials of the wave's rows
+    {
+        const int jc = min(l, n_cols - 1);
+        const int i0 = PSQ * p, i1 = min(i0 + PSQ, n_rows);
+        float gj[DP], wj[DP], aj[DP], ag[DP], av[DP];
+#pragma unroll
+        for (int k = 0; k < DP; ++k) { gj[k] = G[jc * DP + k]; wj[k] = W2[jc * DP + k]; aj[k] = A2[jc * DP + k]; ag[k] = 0.f; av[k] = 0.f; }
+        for (int i = i0; i < i1; ++i) {
+            float tt[DP], rr[DP];
+            float S = 0.f;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float dq = Z[i * DP + k] - gj[k];
+                rr[k] = dq * wj[k];
+                tt[k] = aj[k] - dq * rr[k];
+                S += tt[k];
+            }
+            const float Pij = cP * fexp2(S - LS[i] * LOG2E);
+#pragma unroll
+            for (int k = 0; k < DP; ++k) {
+                const float wt = Pij + cQ * fexp2(tt[k] - (k < d ? LK[i * DP + k] * LOG2E : 0.f));
+                ag[k] += wt * rr[k];
+                av[k] -= wt * (0.5f + LN2 * (tt[k] - aj[k]));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DP; ++k) { pg[(p * DP + k) * PSM + l] = ag[k] * (2.f * LN2); pv[(p * DP + k) * PSM + l] = av[k]; }
+    }
+    __syncthreads();
+
+    // ---- stage 4: fixed-order sums of the four waves' partials
+    for (int e = tid; e < d * PSM; e += PB) {
+        const int k = e / PSM, i = e - k * PSM;
+        if (i < n_rows) rz[(size_t)i * d + k] = ((pr[(0 * DP + k) * PSM + i] + pr[(1 * DP + k) * PSM + i]) + pr[(2 * DP + k) * PSM + i]) + pr[(3 * DP + k) * PSM + i];
+        if (i < n_cols) {
+            cg[(size_t)i * d + k] = ((pg[(0 * DP + k) * PSM + i] + pg[(1 * DP + k) * PSM + i]) + pg[(2 * DP + k) * PSM + i]) + pg[(3 * DP + k) * PSM + i];
+            cv[(size_t)i * d + k] = ((pv[(0 * DP + k) * PSM + i] + pv[(1 * DP + k) * PSM + i]) + pv[(2 * DP + k) * PSM + i]) + pv[(3 * DP + k) * PSM + i];
+        }
+    }
+}
+
+template <int DP>
+static hipError_t launch_small(int n_rows, int n_cols, int d, const IvaeCoef& C, float logMN, const float* z, const float* g,
+                               const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz, float* cg,
+                               float* cv, int n_models, size_t mstride, hipStream_t st) {
+    const int np = 2 * 4 * (DP + 1) > 3 * 4 * DP ? 2 * 4 * (DP + 1) : 3 * 4 * DP;
+    const size_t bytes = (size_t)(5 * PSM * DP + PSM + np * PSM) * sizeof(float);      // <= 53 KB at DP = 12
+    hipLaunchKernelGGL(k_pair_small<DP>, dim3(n_models), dim3(PB), bytes, st, n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi,
+                       lse_s, lse_k, rz, cg, cv, mstride);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ 32 < d <= 64: one wavefront per row / column
 __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
     const float mn = fmaxf(m, m2);
@@ -461,6 +638,11 @@ hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, con
                                v + o, lse_s + o, lse_k + o, cg + o, cv + o);
         }
         return hipGetLastError();
+    }
+    if (n_rows <= PSM && n_cols <= PSM && d <= 12) {
+        if (d <= 4) return launch_small<4>(n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, n_models, mstride, st);
+        if (d <= 8) return launch_small<8>(n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, n_models, mstride, st);
+        return launch_small<12>(n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, n_models, mstride, st);
     }
     PairGeom P = pair_geometry(n_rows, n_cols, d);
     P.n_models = n_models; P.mstride = mstride;
