@@ -127,6 +127,24 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
                   float* loss_out, float* grads,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- many steps on the shape-generic kernels, one call -----------------------------------
+ * n_steps consecutive iterations of   zero_grad -> elbo -> backward -> Adam.step
+ *   runners/ivae.py:75-91   models/wrappers.py:64-70
+ * for ANY shape / activation / loss weights ivae_elbo_fwd_bwd takes, enqueued back to back by one call (the host
+ * side of a training epoch is then one call, not one per step).  Step s reads batch s of
+ *   x_steps (n_steps, n_models, batch, data_dim), u_steps (n_steps, n_models, batch, aux_dim) or NULL,
+ *   eps_steps (n_steps, n_models, batch, latent_dim)
+ * and writes loss_out (n_steps, n_models) and z_steps (n_steps, n_models, batch, latent_dim).
+ * params / exp_avg / exp_avg_sq (n_models, P) in/out; grads (n_models, P): scratch for the flat gradient;
+ * step0 = Adam steps already taken; lr and the loss weights are constant over the call. */
+int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef,
+                         float* params, float* exp_avg, float* exp_avg_sq,
+                         const float* x_steps, const float* u_steps, const float* eps_steps,
+                         int32_t n_steps, int64_t step0,
+                         double lr, double beta1, double beta2, double adam_eps,
+                         float* loss_out, float* z_steps, float* grads,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused persistent training ---------------------------------------------------------
  * n_steps consecutive iterations of   zero_grad -> elbo -> backward -> Adam.step
  *   runners/ivae.py:75-91   models/wrappers.py:64-70   (plain ELBO: models/nets.py:475,599)

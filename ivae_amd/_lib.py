@@ -36,7 +36,7 @@ class IvaeWsLayout(C.Structure):
 
 
 EXPORTS = ["ivae_param_count", "ivae_workspace_bytes", "ivae_workspace_layout", "ivae_elbo_fwd_bwd", "ivae_forward",
-           "ivae_pairwise", "ivae_pairwise_workspace_bytes", "ivae_backward", "ivae_adam_step", "ivae_train_steps", "ivae_train_steps_supported", "ivae_corr_workspace_bytes", "ivae_corr", "ivae_corr_batched",
+           "ivae_pairwise", "ivae_pairwise_workspace_bytes", "ivae_backward", "ivae_adam_step", "ivae_elbo_adam_steps", "ivae_train_steps", "ivae_train_steps_supported", "ivae_corr_workspace_bytes", "ivae_corr", "ivae_corr_batched",
            "ivae_last_hip_error", "ivae_version"]
 
 _lib = None
@@ -61,6 +61,8 @@ def lib():
     L.ivae_pairwise.argtypes = [C.c_int32, C.c_int32, C.c_int32, pc, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_backward.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, f64, f64, f64, f64, C.c_int64, vp]
+    L.ivae_elbo_adam_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int64, f64, f64, f64, f64, vp, vp, vp, vp,
+                                       C.c_size_t, vp]
     L.ivae_train_steps_supported.argtypes = [pd]
     L.ivae_train_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_uint64, C.c_int32, C.c_int64,
                                    f64, f64, f64, f64, vp, vp, vp, vp]

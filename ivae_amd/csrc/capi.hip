@@ -134,6 +134,32 @@ int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_adam_step");
 }
 
+int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
+                         const float* x_steps, const float* u_steps, const float* eps_steps, int32_t n_steps,
+                         int64_t step0, double lr, double beta1, double beta2, double adam_eps, float* loss_out,
+                         float* z_steps, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = ivae_check_dims(dims);
+    if (rc) return rc;
+    if (n_steps <= 0 || step0 < 0) return IVAE_E_BADDIMS;
+    if (!params || !exp_avg || !exp_avg_sq || !x_steps || !eps_steps || !loss_out || !z_steps || !grads ||
+        (dims->aux_dim > 0 && !u_steps))
+        return IVAE_E_NULLPTR;
+    int64_t P = 0;
+    if ((rc = ivae_param_count(dims, &P))) return rc;
+    const size_t rows = (size_t)dims->n_models * dims->batch;
+    for (int s = 0; s < n_steps; ++s) {
+        rc = ivae_elbo_fwd_bwd(dims, coef, params, x_steps + s * rows * dims->data_dim,
+                               u_steps ? u_steps + s * rows * dims->aux_dim : nullptr, eps_steps + s * rows * dims->latent_dim,
+                               z_steps + s * rows * dims->latent_dim, loss_out + (size_t)s * dims->n_models, grads, workspace,
+                               workspace_bytes, stream);
+        if (rc) return rc;
+        rc = ivae_adam_step(params, exp_avg, exp_avg_sq, grads, P * dims->n_models, lr, beta1, beta2, adam_eps, step0 + s + 1,
+                            stream);
+        if (rc) return rc;
+    }
+    return IVAE_OK;
+}
+
 int ivae_train_steps_supported(const IvaeDims* d) {
     if (ivae_check_dims(d) != IVAE_OK) return 0;
     if (!(d->slope >= 0.f && d->slope <= 1.f)) return 0;      // the fused kernel computes lrelu as max(p, slope*p)

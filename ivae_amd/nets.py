@@ -198,6 +198,21 @@ class _FusedModel(nn.Module):
         optimizer.step_flat(flat, grads)
         return loss[0], z
 
+    def direct_steps(self, optimizer, xs, us, a, b, c, d, N, pairwise, eps=None, z_out=None):
+        """`direct_step` over the batches xs (n, B, data_dim) [us (n, B, aux_dim)] with ONE library call
+        (`ivae_elbo_adam_steps`): same kernels, same update, constant loss weights and learning rate over the call; the
+        noise of all n steps is one torch.randn draw.  Returns (losses (n,), z (n, B, latent_dim))."""
+        if eps is None:
+            eps = torch.randn(xs.shape[0], xs.shape[1], self._shape.latent_dim, dtype=torch.float32, device=xs.device)
+        coef = ops.make_coef(a, b, c, d, N, self._decoder_var_f, pairwise, xs.shape[1])
+        flat = self._flat_params()
+        m, v, taken, group = optimizer.flat_state(flat)
+        b1, b2 = group['betas']
+        loss, z = ops.elbo_adam_steps(self._shape, coef, flat, m, v, xs, us, eps, self._ws, taken, group['lr'], b1, b2,
+                                      group['eps'], z_out=z_out)
+        optimizer.advance(xs.shape[0])
+        return loss[:, 0], z
+
     def _loss(self, x, u, a, b, c, d, N, pairwise, eps=None):
         eps = self._eps(x, eps)
         coef = ops.make_coef(a, b, c, d, N, self._decoder_var_f, pairwise, x.shape[0])

@@ -133,6 +133,40 @@ def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, z_out=None):
     return loss, z, grads
 
 
+def elbo_adam_steps(shape, coef, params, exp_avg, exp_avg_sq, x_steps, u_steps, eps_steps, ws, step0, lr, beta1=0.9,
+                    beta2=0.999, adam_eps=1e-8, n_models=1, z_out=None):
+    """ivae_elbo_adam_steps: x_steps (n_steps, [n_models,] batch, data_dim) etc.; params and the Adam moments are
+    updated in place.  -> (loss (n_steps, n_models), z (like eps_steps))."""
+    x_steps = _f32c(x_steps, "x_steps")
+    eps_steps = _f32c(eps_steps, "eps_steps")
+    u_steps = _f32c(u_steps, "u_steps") if shape.aux_dim > 0 else None
+    for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError(f"{n} must be a contiguous float32 ROCm tensor")
+    n_steps, B = x_steps.shape[0], x_steps.shape[-2]
+    if eps_steps.shape[0] != n_steps or (u_steps is not None and u_steps.shape[0] != n_steps):
+        raise ValueError("x_steps, u_steps and eps_steps hold different numbers of steps")
+    if params.numel() != n_models * shape.n_params() or exp_avg.numel() != params.numel() or exp_avg_sq.numel() != params.numel():
+        raise ValueError("params / exp_avg / exp_avg_sq do not hold n_models * n_params floats")
+    dims = shape.dims(B, n_models)
+    dev = x_steps.device
+    with torch.cuda.device(dev):
+        buf = ws.get(dims, dev)
+        if z_out is None:
+            z = torch.empty_like(eps_steps)
+        else:
+            z = z_out
+            if (z.dtype != torch.float32 or not z.is_contiguous() or z.device != dev or z.numel() != eps_steps.numel()):
+                raise ValueError("z_out must be a contiguous float32 tensor of eps_steps' size on the inputs' device")
+        loss = torch.empty(n_steps, n_models, dtype=torch.float32, device=dev)
+        grads = torch.empty_like(params)
+        check(_lib.lib().ivae_elbo_adam_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                              _ptr(x_steps), _ptr(u_steps), _ptr(eps_steps), int(n_steps), int(step0),
+                                              float(lr), float(beta1), float(beta2), float(adam_eps), _ptr(loss), _ptr(z),
+                                              _ptr(grads), _ptr(buf), buf.numel() * 4, _stream(dev)), "ivae_elbo_adam_steps")
+    return loss, z
+
+
 def forward(shape, coef, params, x, u, eps, ws, n_models=1):
     """ivae_forward: fills the workspace row tensors, returns z."""
     x = _f32c(x, "x")

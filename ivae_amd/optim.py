@@ -49,6 +49,30 @@ class FusedAdam(torch.optim.Optimizer):
         ops.adam_step(flat_p, self._flat[1], self._flat[2], flat_g, group['lr'], self._step0 + self._pending, b1, b2,
                       group['eps'])
 
+    def flat_state(self, flat_p):
+        """-> (exp_avg, exp_avg_sq, steps_taken, group) as flat buffers over `flat_p`, for callers that run several
+        updates in one library call (`ivae_elbo_adam_steps`) and then report them with `advance(n)`."""
+        if len(self.param_groups) != 1:
+            raise RuntimeError('flat_state needs a single parameter group')
+        group = self.param_groups[0]
+        plist = group['params']
+        if self._flat is None or self._flat_key is not plist or len(plist) != len(self._flat[0]):
+            ps = tuple(plist)
+            self._sync_steps()
+            if any(len(self.state[p]) == 0 for p in ps):
+                self._init_group_state(list(ps))
+            m = self._flat_view([self.state[p]['exp_avg'] for p in ps])
+            v = self._flat_view([self.state[p]['exp_avg_sq'] for p in ps])
+            if m is None or v is None or m.numel() != flat_p.numel():
+                raise RuntimeError('optimizer state is not one flat buffer over these parameters')
+            self._flat, self._flat_key = (ps, m, v), plist
+            self._step0 = int(self.state[ps[0]]['step'])
+        return self._flat[1], self._flat[2], self._step0 + self._pending, group
+
+    def advance(self, n):
+        """Record n updates done through the buffers of `flat_state`."""
+        self._pending += int(n)
+
     def state_dict(self):
         self._sync_steps_keep()
         return super().state_dict()

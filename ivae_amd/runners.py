@@ -98,15 +98,11 @@ def runner(args, config):
             nb = N // B
             perm = torch.randperm(N, device=device, generator=gen)[:nb * B]
             Xe, Ue, Se = X[perm].view(nb, B, -1), U[perm].view(nb, B, -1), S[perm].view(nb, B, -1)
-            loss_sum = torch.zeros((), device=device)
             Ze = torch.empty(nb, B, d_latent, device=device)
-            for i in range(nb):
-                # zero_grad -> elbo -> backward -> step (runners/ivae.py:75-91) as one launch sequence
-                loss, _ = model.direct_step(optimizer, Xe[i], Ue[i] if config.ica else None, a, b, c, d, N, True,
-                                            z_out=Ze[i])
-                loss_sum += loss
+            # zero_grad -> elbo -> backward -> step (runners/ivae.py:75-91) of the whole epoch enqueued by one call
+            losses, _ = model.direct_steps(optimizer, Xe, Ue if config.ica else None, a, b, c, d, N, True, z_out=Ze)
             cc = ops.corr_batched(Se, Ze)       # the per-step batch scores (runners/ivae.py:86), one launch per epoch
-            train_loss = float(loss_sum.item()) / nb          # the epoch's one sync
+            train_loss = float(losses.sum().item()) / nb      # the epoch's one sync
             train_perf = float(np.mean(_assignment_scores(cc.abs().cpu().numpy())))
             perf_hist.append(train_perf)
             loss_hist.append(train_loss)
@@ -229,7 +225,18 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
         else:
             n_full = N // batch_size
             Ze = torch.empty(n_full, batch_size, d, device=device) if cc is not None else None
+            first = 0
+            if not anneal and n_full:
+                # constant loss weights: the epoch's full batches go through ONE ivae_elbo_adam_steps call
+                idx = torch.stack(batches[:n_full])
+                losses, _ = model.direct_steps(optimizer, X[idx], U[idx] if with_u else None, 1., 1., 1., 1., 1., False,
+                                               z_out=Ze)
+                logger.update('elbo', losses.sum(), weight=n_full)
+                it += n_full
+                first = n_full
             for i, bidx in enumerate(batches):
+                if i < first:
+                    continue
                 it += 1
                 full = Ze is not None and i < n_full
                 if anneal:

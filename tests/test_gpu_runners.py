@@ -135,3 +135,46 @@ def test_direct_step_equals_drop_in_sequence():
     for k in s1:
         assert float(s1[k]['step']) == float(s2[k]['step']) == 6.0
         assert torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) and torch.equal(s1[k]['exp_avg_sq'], s2[k]['exp_avg_sq'])
+
+
+@pytest.mark.parametrize("family", ["cleanivae", "cleanvae"])
+def test_direct_steps_equals_direct_step_sequence(family):
+    """model.direct_steps (ivae_elbo_adam_steps: an epoch's steps enqueued by one library call) is the same
+    computation as a loop of direct_step with the same noise: losses, z, parameters and optimizer state agree bit
+    for bit, also when a direct_step precedes and follows it (step counts carry over)."""
+    import copy
+    import torch
+    from ivae_amd import FusedAdam, cleanIVAE, cleanVAE
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    if family == "cleanivae":
+        m1 = cleanIVAE(data_dim=5, latent_dim=5, aux_dim=40, hidden_dim=100, n_layers=3, activation='xtanh').to(dev)
+    else:
+        m1 = cleanVAE(data_dim=5, latent_dim=5, hidden_dim=100, n_layers=3, activation='xtanh').to(dev)
+    m2 = copy.deepcopy(m1)
+    o1, o2 = FusedAdam(m1.parameters(), lr=1e-2), FusedAdam(m2.parameters(), lr=1e-2)
+    g = torch.Generator(device=dev).manual_seed(0)
+    n = 7
+    xs = torch.randn(n, 64, 5, generator=g, device=dev)
+    us = None
+    if family == "cleanivae":
+        us = torch.zeros(n, 64, 40, device=dev)
+        us.view(-1, 40)[torch.arange(n * 64), torch.randint(0, 40, (n * 64,), generator=g, device=dev)] = 1
+    eps = torch.randn(n, 64, 5, generator=g, device=dev)
+    w = (100., 1., 0., 10., 40000, True)
+    u_at = (lambda i: us[i]) if us is not None else (lambda i: None)
+    l1 = [m1.direct_step(o1, xs[i], u_at(i), *w, eps=eps[i]) for i in range(n)]
+    first = m2.direct_step(o2, xs[0], u_at(0), *w, eps=eps[0])
+    zbuf = torch.empty(n - 2, 64, 5, device=dev)
+    lm, zm = m2.direct_steps(o2, xs[1:n - 1], None if us is None else us[1:n - 1], *w, eps=eps[1:n - 1], z_out=zbuf)
+    last = m2.direct_step(o2, xs[n - 1], u_at(n - 1), *w, eps=eps[n - 1])
+    assert torch.equal(first[0], l1[0][0]) and torch.equal(last[0], l1[n - 1][0]) and torch.equal(last[1], l1[n - 1][1])
+    for i in range(1, n - 1):
+        assert torch.equal(lm[i - 1], l1[i][0]) and torch.equal(zm[i - 1], l1[i][1])
+    assert zm.data_ptr() == zbuf.data_ptr()
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(p1, p2)
+    s1, s2 = o1.state_dict()['state'], o2.state_dict()['state']
+    for k in s1:
+        assert float(s1[k]['step']) == float(s2[k]['step']) == float(n)
+        assert torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) and torch.equal(s1[k]['exp_avg_sq'], s2[k]['exp_avg_sq'])
