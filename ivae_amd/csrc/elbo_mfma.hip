@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * NW) void k_wgrad(Layout L, const float* __rest
                                                    float* __restrict__ slabs, long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GEOM(NW);
-    const int TR = L.tr;
+    const int TR = L.trw;                   // rows of this kernel's tiles (its own tiling: the contraction length)
     float* wbuf = smem;
     float* dT = wbuf + 2 * CHUNK;           // delta transposed (n, ldr)
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(NR) void k_reduce(Layout L, IvaeCoef C, const float
                                                float* __restrict__ grads, float* __restrict__ loss_out) {
     const int model = blockIdx.y;
     const float* wsm = ws + (size_t)model * L.ws.per_model;
-    const int nblk_p = L.n_tiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;   // one tile: the kernels wrote grads directly
+    const int nblk_p = L.n_wtiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;   // one tile: the kernels wrote grads directly
     __shared__ float red[NR];
     if ((int)blockIdx.x < nblk_p) {
         const int p = min((int)blockIdx.x * RED_P + (int)(threadIdx.x & 63), L.n_params - 1);
@@ -726,13 +726,13 @@ __global__ __launch_bounds__(NR) void k_reduce(Layout L, IvaeCoef C, const float
         const float* s = wsm + L.ws_partial + p;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int t = g;
-        for (; t + 12 < L.n_tiles; t += 16) {
+        for (; t + 12 < L.n_wtiles; t += 16) {
             a0 += s[(size_t)t * L.n_params];
             a1 += s[(size_t)(t + 4) * L.n_params];
             a2 += s[(size_t)(t + 8) * L.n_params];
             a3 += s[(size_t)(t + 12) * L.n_params];
         }
-        for (; t < L.n_tiles; t += 4) a0 += s[(size_t)t * L.n_params];
+        for (; t < L.n_wtiles; t += 4) a0 += s[(size_t)t * L.n_params];
         red[threadIdx.x] = (a0 + a1) + (a2 + a3);
         __syncthreads();
         if (g == 0 && (int)blockIdx.x * RED_P + (int)threadIdx.x < L.n_params)
@@ -787,8 +787,8 @@ static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const f
     constexpr int NT = 64 * NW;
     const int nz = L.M > 0 ? 3 : 2;
     // gradient slabs: per-tile partials in the workspace, or the caller's gradient buffer itself when a model is one tile
-    float* slabs = L.n_tiles > 1 ? ws + L.ws_partial : grads;
-    const long slab_stride = L.n_tiles > 1 ? (long)L.ws.per_model : (long)L.n_params;
+    float* slabs = L.n_wtiles > 1 ? ws + L.ws_partial : grads;
+    const long slab_stride = L.n_wtiles > 1 ? (long)L.ws.per_model : (long)L.n_params;
     hipError_t e;
     if (what == 0) {            // encoder / prior forward
         if ((e = set_smem((const void*)k_fwd_enc<RTE, NW>, L.smem_enc, cur_enc)) != hipSuccess) return e;
@@ -798,7 +798,7 @@ static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const f
         hipLaunchKernelGGL((k_dec<RTE, NW>), dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws);
     } else if (what == 5) {     // weight gradients of every layer of every MLP
         if ((e = set_smem((const void*)k_wgrad<NW>, L.smem_wg, cur_wg)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_wgrad<NW>), dim3(L.n_tiles, L.n_models, (nz + 1) * L.L), dim3(NT), L.smem_wg, st, L, params, x, u, ws,
+        hipLaunchKernelGGL((k_wgrad<NW>), dim3(L.n_wtiles, L.n_models, (nz + 1) * L.L), dim3(NT), L.smem_wg, st, L, params, x, u, ws,
                            slabs, slab_stride);
     } else {                    // encoder / prior input-gradient chains
         if ((e = set_smem((const void*)k_bwd_enc<RTE, NW>, L.smem_benc, cur_benc)) != hipSuccess) return e;
@@ -841,7 +841,7 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
     if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     if ((e = launch_phase(L, C, 4, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
-    const int nblk_p = L.n_tiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
+    const int nblk_p = L.n_wtiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
     if (nblk_p == 0 && !loss_out) return hipSuccess;
     hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(NR), 0, st, L, C, ws, grads, loss_out);
     return hipGetLastError();

@@ -34,10 +34,11 @@ struct Layout {
     int maxh;            // widest row among hidden / output tensors
     // workspace (float offsets per model)
     IvaeWsLayout ws;
-    int64_t ws_partial;  // (n_tiles, n_params) per-tile gradient slabs
+    int64_t ws_partial;  // (n_wtiles, n_params) per-tile gradient slabs
     int64_t ws_pair;     // scratch of the pairwise kernels for a (B, B, dl) problem
     // row tiling of k_fwd_enc / k_dec / k_bwd_enc (elbo_mfma.hip)
     int tr, n_tiles;     // rows per workgroup (16, 32 or 64), workgroups per model
+    int trw, n_wtiles;   // rows per workgroup of k_wgrad (the contraction length of a weight gradient: 64 .. 256), its tiles
     int nw;              // waves per workgroup (4, 8 or 16): a streamed operand chunk holds 16 nw output columns
     int Bp;              // batch rounded up to 64: leading dimension of the feature-major pre-activations
     int uoff;            // column of u inside the [x | pad | u | 1] input tile (multiple of 4)
@@ -64,17 +65,15 @@ static inline void ivae_tile_geometry(Layout& L, int tr, int nw) {
     L.lds = ivae_ld4o(ivae_up16(L.dl + 1));
     L.ldd = ivae_ld4o(ivae_up16(wide));
     L.nT = ivae_up16(wide);
-    L.ldr = tr + 4;
     // +64 floats: k-steps past a tile's last column read (finite) neighbours; the last tile needs room for that
     const int ldt = L.ldh > L.ldd ? L.ldh : L.ldd;
     L.smem_enc = 4 * (2 * chunk + tr * L.ldx + 2 * tr * L.ldh + 64);
     L.smem_dec = 4 * (2 * chunk + 2 * tr * ldt + 2 * tr * L.lds + 64);
     L.smem_benc = 4 * (2 * chunk + 2 * tr * L.ldd + 64);
-    L.smem_wg = 4 * (2 * chunk + L.nT * L.ldr + 64);
 }
 
 static inline bool ivae_lds_over(const Layout& L) {
-    return L.smem_enc > IVAE_LDS_LIMIT || L.smem_dec > IVAE_LDS_LIMIT || L.smem_benc > IVAE_LDS_LIMIT || L.smem_wg > IVAE_LDS_LIMIT;
+    return L.smem_enc > IVAE_LDS_LIMIT || L.smem_dec > IVAE_LDS_LIMIT || L.smem_benc > IVAE_LDS_LIMIT;
 }
 
 static inline int ivae_check_dims(const IvaeDims* d) {
@@ -153,7 +152,27 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     }
     if (ivae_lds_over(L)) return IVAE_E_TOOLARGE;
     L.n_tiles = (L.B + tr - 1) / tr;
-    L.ws_partial = take((int64_t)L.n_tiles * L.n_params);
+    // k_wgrad's own row tiling: a weight gradient contracts over the batch rows, so its workgroups take as many rows
+    // (16 .. 256) as still leaves the chip two workgroups per CU (and fits 64 KB of LDS): fewer, longer contractions per
+    // chunk round trip and fewer slabs for k_reduce; launches too small to fill the chip keep 16-row tiles (measured)
+    {
+        const int64_t prods = (int64_t)(L.M > 0 ? 4 : 3) * L.L * L.n_models;
+        int trw = L.Bp < 256 ? L.Bp : 256;       // (Bp is a multiple of 64)
+        if (trw == 192) trw = 128;
+        auto smem = [&](int t) { return 4 * (2 * IVAE_CHUNK_FLOATS(L.nw) + L.nT * (t + 4) + 64); };
+        while (trw > 16 && ((int64_t)((L.B + trw - 1) / trw) * prods < 512 || smem(trw) > 64 * 1024)) trw >>= 1;
+        if (const char* e = getenv("IVAE_AMD_WGRAD_ROWS")) {       // tuning knob: 16, 32, 64, 128 or 256
+            const int v = atoi(e);
+            if (v == 16 || v == 32 || v == 64 || v == 128 || v == 256) trw = v;
+        }
+        while (trw > 16 && smem(trw) > IVAE_LDS_LIMIT) trw >>= 1;
+        if (smem(trw) > IVAE_LDS_LIMIT) return IVAE_E_TOOLARGE;
+        L.trw = trw;
+        L.ldr = trw + 4;
+        L.smem_wg = smem(trw);
+        L.n_wtiles = (L.B + trw - 1) / trw;
+    }
+    L.ws_partial = take((int64_t)L.n_wtiles * L.n_params);
     L.ws_dz = take(Bl);
     L.ws_pair = take((int64_t)ivae_pair_ws_floats(L.B, L.B, L.dl));
     wso = (wso + 63) & ~(int64_t)63;

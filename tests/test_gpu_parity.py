@@ -372,3 +372,21 @@ def test_corr_batched_matches_numpy_corrcoef(nb, n, d):
         assert np.abs(cc[b] - ref).max() < 1e-12
         one = ops.corr(t(x[b]), t(y[b])).cpu().numpy()
         assert np.abs(cc[b] - one).max() < 1e-12
+
+
+@pytest.mark.parametrize("wgrad_rows", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("name", ["ivae_plain_b70", "cleanvae_btcvae_b200", "ivae_plain_cfg4s"])
+def test_every_wgrad_row_tiling_matches_reference_fixture(name, wgrad_rows, monkeypatch):
+    """k_wgrad tiles the batch on its own (its rows are the contraction length of a weight gradient);
+    IVAE_AMD_WGRAD_ROWS pins the tile so that every contraction length (one to four k chunks, ragged last tiles, tiles
+    longer than the batch) meets the same 1e-5 bar."""
+    monkeypatch.setenv("IVAE_AMD_WGRAD_ROWS", str(wgrad_rows))
+    c = Case(name)
+    loss, z, grads, ws = run_case(c)
+    assert abs(float(loss[0]) - c.loss()) <= TOL * abs(c.loss())
+    g = grads.cpu().numpy()
+    off = 0
+    for n in c.spec.param_names():
+        ref = c.grads[n]
+        assert relmax(g[off:off + ref.size].reshape(ref.shape), ref) < TOL, (n, wgrad_rows)
+        off += ref.size
