@@ -608,27 +608,36 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
                          }
                      });
         __syncthreads();
-        // per-row Gaussian log-densities   (models/nets.py:306-314, 45-52)
-        if (tid < nrows) {
-            const int r = tid;
+        // per-row Gaussian log-densities   (models/nets.py:306-314, 45-52): four lanes per row take every fourth
+        // feature, then two xor-shuffles add the partial sums (fixed order)
+        {
+            const int r = tid >> 2, part = tid & 3;
+            const bool live = r < nrows;                // (tid < 4 TR <= NT: whole waves take the same branch below)
+            const int rr = live ? r : 0;
             const float dv = C.decoder_var;
             const float logdv = logf(dv);
             float lpx = 0.f, lqc = 0.f, lp = 0.f;
-            for (int k = 0; k < L.dd; ++k) {
-                const float df = xm[(size_t)r * L.dd + k] - fm[(size_t)r * L.dd + k];
-                lpx += -0.5f * (LOG2PI + logdv + df * df / dv);
+            if (tid < 4 * TR) {
+                for (int k = part; k < L.dd; k += 4) {
+                    const float df = xm[(size_t)rr * L.dd + k] - fm[(size_t)rr * L.dd + k];
+                    lpx += -0.5f * (LOG2PI + logdv + df * df / dv);
+                }
+                for (int k = part; k < L.dl; k += 4) {
+                    const size_t o = (size_t)(row0 + rr) * L.dl + k;
+                    const float zz = sz[rr * lds + k], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o];
+                    const float ll = L.M > 0 ? wsm[L.ws.l + o] : 1.f;
+                    const float dq = zz - gg;
+                    lqc += -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
+                    lp += -0.5f * (LOG2PI + logf(ll) + zz * zz / ll);
+                }
+                lpx += __shfl_xor(lpx, 1); lqc += __shfl_xor(lqc, 1); lp += __shfl_xor(lp, 1);
+                lpx += __shfl_xor(lpx, 2); lqc += __shfl_xor(lqc, 2); lp += __shfl_xor(lp, 2);
+                if (live && part == 0) {
+                    wsm[L.ws.lpx + row0 + r] = lpx;
+                    wsm[L.ws.lqc + row0 + r] = lqc;
+                    wsm[L.ws.lp + row0 + r] = lp;
+                }
             }
-            for (int k = 0; k < L.dl; ++k) {
-                const size_t o = (size_t)(row0 + r) * L.dl + k;
-                const float zz = sz[r * lds + k], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o];
-                const float ll = L.M > 0 ? wsm[L.ws.l + o] : 1.f;
-                const float dq = zz - gg;
-                lqc += -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
-                lp += -0.5f * (LOG2PI + logf(ll) + zz * zz / ll);
-            }
-            wsm[L.ws.lpx + row0 + r] = lpx;
-            wsm[L.ws.lqc + row0 + r] = lqc;
-            wsm[L.ws.lp + row0 + r] = lp;
         }
     }
     MSTAMP(200);
