@@ -111,11 +111,7 @@ def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2
         steps = epochs * (N // batch)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        if fused:
-            tr.run(steps)
-        else:
-            for _ in range(steps):
-                tr.step()
+        tr.run(steps)            # fused: ivae_train_steps launches; generic: one ivae_elbo_adam_steps call per epoch
         torch.cuda.synchronize(device)
         t_train += time.perf_counter() - t0
         work += steps * len(seeds)

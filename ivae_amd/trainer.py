@@ -96,6 +96,26 @@ class PackedTrainer:
         self._loss, self._z = loss, z
         return loss
 
+    def run(self, n_steps):
+        """n_steps steps with one `ivae_elbo_adam_steps` call per stretch of an epoch (same kernels and update as
+        `step`; the noise of a stretch is one draw)."""
+        done = 0
+        while done < n_steps:
+            if self._batches is None or self._cursor >= self._batches:
+                self._reshuffle()
+            k = min(n_steps - done, self._batches - self._cursor)
+            xs = self._bx[self._cursor:self._cursor + k]
+            us = self._bu[self._cursor:self._cursor + k] if self.shape.aux_dim > 0 else None
+            eps = torch.randn(k, self.M, self.B, self.shape.latent_dim, generator=self.gen, device=self.dev)
+            coef = ops.make_coef(N=self.N, decoder_var=self.decoder_var, global_batch=self.B, **self.coef_kw)
+            loss, z = ops.elbo_adam_steps(self.shape, coef, self.params.view(-1), self.exp_avg.view(-1),
+                                          self.exp_avg_sq.view(-1), xs, us, eps, self.ws, self.t, self.lr, n_models=self.M)
+            self._cursor += k
+            self.t += k
+            done += k
+            self._loss, self._z = loss[-1], z[-1]
+        return self._loss
+
     def losses(self):
         return self._loss
 
