@@ -662,13 +662,31 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     }
 }
 
+// Thread t's share (rows t, t + NR, ...) of the sum over rows of the per-row ELBO terms.
+__device__ __forceinline__ float loss_partial(const Layout& L, const IvaeCoef& C, const float* wsm, int t) {
+    float acc = 0.f;
+    for (int i = t; i < L.B; i += NR) {
+        const float lpx = wsm[L.ws.lpx + i], lqc = wsm[L.ws.lqc + i], lp = wsm[L.ws.lp + i];
+        float row;
+        if (C.pairwise) {
+            const float lq = wsm[L.ws.lq + i], lqi = wsm[L.ws.lqi + i];
+            row = C.a * lpx - C.b * (lqc - lq) - C.c * (lq - lqi) - C.d * (lqi - lp);
+        } else {
+            row = C.a * lpx - C.b * lqc + C.d * lp;
+        }
+        acc += row;
+    }
+    return acc;
+}
+
 // Encoder / prior backward.  blockIdx.z picks the MLP: 0 = g, 1 = logv, 2 = logl (three concurrent workgroups per row
 // tile).  Forms the output-layer delta of its head (SURVEY.md §8 a-bwd; pairwise terms included) and runs the
 // input-gradient chain; the deltas go to the workspace for k_wgrad.
 template <int RTE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const float* __restrict__ params,
                                                 const float* __restrict__ x, const float* __restrict__ u,
-                                                const float* __restrict__ eps, float* __restrict__ ws) {
+                                                const float* __restrict__ eps, float* __restrict__ ws,
+                                                float* __restrict__ loss_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GEOM(NW);
     const int TR = L.tr;
@@ -717,6 +735,18 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
     }
     mlp_bwd<RTE, NW>(L, X, L.mlp[m], nullptr, 0, src_none(), St);
     MSTAMP(202);
+    // loss of the model (loss_out != null: no slab reduction follows, so k_reduce is not launched): one workgroup sums
+    // the per-row terms with k_reduce's thread map and order (same bits)
+    if (loss_out && blockIdx.x == 0 && blockIdx.z == 0) {
+        __syncthreads();
+        if (tid < NR) wbuf[tid] = loss_partial(L, C, wsm, tid);
+        __syncthreads();
+        for (int s = NR / 2; s > 0; s >>= 1) {
+            if (tid < s) wbuf[tid] += wbuf[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0) loss_out[model] = -wbuf[0] / (float)C.global_batch;
+    }
 }
 
 // Sum the per-tile slabs into grads and reduce the loss.  A block sums 64 parameters: wave g adds the tiles
@@ -750,18 +780,7 @@ __global__ __launch_bounds__(NR) void k_reduce(Layout L, IvaeCoef C, const float
         return;
     }
     if (!loss_out) return;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < L.B; i += NR) {
-        const float lpx = wsm[L.ws.lpx + i], lqc = wsm[L.ws.lqc + i], lp = wsm[L.ws.lp + i];
-        float row;
-        if (C.pairwise) {
-            const float lq = wsm[L.ws.lq + i], lqi = wsm[L.ws.lqi + i];
-            row = C.a * lpx - C.b * (lqc - lq) - C.c * (lq - lqi) - C.d * (lqi - lp);
-        } else {
-            row = C.a * lpx - C.b * lqc + C.d * lp;
-        }
-        acc += row;
-    }
+    const float acc = loss_partial(L, C, wsm, threadIdx.x);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = NR / 2; s > 0; s >>= 1) {
@@ -811,7 +830,8 @@ static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const f
                            slabs, slab_stride);
     } else {                    // encoder / prior input-gradient chains
         if ((e = set_smem((const void*)k_bwd_enc<RTE, NW>, L.smem_benc, cur_benc)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_bwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws);
+        hipLaunchKernelGGL((k_bwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws,
+                           z_out /* phase 4: the loss output, or null */);
     }
     return hipGetLastError();
 }
@@ -848,10 +868,11 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
                            const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st) {
     hipError_t e;
     if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
-    if ((e = launch_phase(L, C, 4, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
-    if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     const int nblk_p = L.n_wtiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
-    if (nblk_p == 0 && !loss_out) return hipSuccess;
+    // no slabs to sum: k_bwd_enc also reduces the loss and k_reduce is not launched
+    if ((e = launch_phase(L, C, 4, params, x, u, eps, nblk_p == 0 ? loss_out : nullptr, ws, grads, st)) != hipSuccess) return e;
+    if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
+    if (nblk_p == 0) return hipSuccess;
     hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(NR), 0, st, L, C, ws, grads, loss_out);
     return hipGetLastError();
 }
