@@ -70,10 +70,11 @@ static inline void ivae_tile_geometry(Layout& L, int tr, int nw) {
     L.smem_enc = 4 * (2 * chunk + tr * L.ldx + 2 * tr * L.ldh + 64);
     L.smem_dec = 4 * (2 * chunk + 2 * tr * ldt + 2 * tr * L.lds + 64);
     L.smem_benc = 4 * (2 * chunk + 2 * tr * L.ldd + 64);
+    L.smem_wg = 4 * (2 * chunk + L.nT * (16 + 4) + 64);      // with k_wgrad's smallest row tile; final value: ivae_make_layout
 }
 
 static inline bool ivae_lds_over(const Layout& L) {
-    return L.smem_enc > IVAE_LDS_LIMIT || L.smem_dec > IVAE_LDS_LIMIT || L.smem_benc > IVAE_LDS_LIMIT;
+    return L.smem_enc > IVAE_LDS_LIMIT || L.smem_dec > IVAE_LDS_LIMIT || L.smem_benc > IVAE_LDS_LIMIT || L.smem_wg > IVAE_LDS_LIMIT;
 }
 
 static inline int ivae_check_dims(const IvaeDims* d) {

@@ -29,9 +29,14 @@ def _case(seed):
     return dd, dl, M, H, L, act, B, pairwise, n_models
 
 
-@pytest.mark.parametrize("seed", range(40))
+WIDE = {100: (10, 10, 40, 600, 3, "lrelu", 70, False, 1),      # hidden widths whose tiles leave the LDS no room for the
+        101: (5, 5, 40, 896, 2, "xtanh", 20, True, 1),         # widest workgroups: the layout falls back to fewer waves
+        102: (33, 12, 130, 300, 3, "sigmoid", 300, False, 2)}
+
+
+@pytest.mark.parametrize("seed", list(range(40)) + sorted(WIDE))
 def test_random_shape_matches_fp64_oracle(seed):
-    dd, dl, M, H, L, act, B, pairwise, n_models = _case(seed)
+    dd, dl, M, H, L, act, B, pairwise, n_models = WIDE[seed] if seed in WIDE else _case(seed)
     spec = np_ref.Spec(data_dim=dd, latent_dim=dl, aux_dim=M, hidden_dim=H, n_layers=L, activation=act, slope=.1,
                        decoder_var=.1)
     rng = np.random.RandomState(seed)
