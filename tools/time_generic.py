@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time one (elbo fwd+bwd [+pairwise] + Adam) step of the shape-generic path at the non-headline BASELINE configs.
-usage: time_generic.py [cfg ...]   cfg in: cfg0 cfg2 cfg3 cfg1g   (BASELINE.json configs[0], [2], [3]; [1] on generic kernels)
+usage: time_generic.py [cfg ...]   cfg in: cfg0 cfg2 cfg3 cfg1g cfgw cfg3p   (BASELINE.json configs[0], [2], [3]; [1] on generic kernels)
 Prints ms/step, samples/s and the dense-equivalent fp32 FLOP fraction per config."""
 import os
 import sys
@@ -16,6 +16,7 @@ CFG = {
     "cfg1g": (ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1), 64, dict(pairwise=False), 40000),
     "cfg2": (ops.ModelShape(5, 5, 0, 100, 3, "xtanh", .1), 1024, dict(a=1000., b=1., c=15., d=1., pairwise=True, decoder_var=.1), 40000),
     "cfg3": (ops.ModelShape(20, 20, 200, 50, 3, "lrelu", .1), 4096, dict(pairwise=False), 1000000),
+    "cfgw": (ops.ModelShape(10, 10, 40, 200, 3, "lrelu", .1), 256, dict(pairwise=False), 40000),   # IVAE_wrapper defaults (wrappers.py:14-16)
     "cfg3p": (ops.ModelShape(20, 20, 200, 50, 3, "lrelu", .1), 4096, dict(a=1., b=1., c=2., d=1., pairwise=True), 1000000),
 }
 
