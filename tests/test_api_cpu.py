@@ -49,6 +49,23 @@ def test_bad_shapes_return_error_codes():
     assert nb.value > 64 * 400 * 4
     assert L.ivae_corr_workspace_bytes(1, 5, C.byref(nb)) == -1
     assert L.ivae_adam_step(None, None, None, None, 10, .01, .9, .999, 1e-8, 1, None) == -3
+    # the many-steps entry point validates before it launches anything: null buffers, step counts, dims
+    good = _lib.IvaeDims(64, 10, 10, 40, 50, 3, 1, .1, 1)
+    coef = ops.make_coef(global_batch=64)
+    args = lambda dims, n, t0: (C.byref(dims), C.byref(coef), None, None, None, None, None, None, n, t0, .01, .9, .999, 1e-8,
+                                None, None, None, None, 0, None)
+    assert L.ivae_elbo_adam_steps(*args(good, 3, 0)) == -3
+    assert L.ivae_elbo_adam_steps(*args(good, 0, 0)) == -1
+    assert L.ivae_elbo_adam_steps(*args(good, 3, -1)) == -1
+    assert L.ivae_elbo_adam_steps(*args(_lib.IvaeDims(64, 10, 10, 40, 50, 3, 9, .1, 1), 3, 0)) == -2
+    # every row tiling / wave count the knobs can pin yields a layout (and a workspace size) for the yaml shapes
+    for rows, waves, wrows in ((16, 4, 16), (64, 16, 256), (32, 8, 64)):
+        os.environ.update(IVAE_AMD_TILE_ROWS=str(rows), IVAE_AMD_WAVES=str(waves), IVAE_AMD_WGRAD_ROWS=str(wrows))
+        try:
+            assert L.ivae_workspace_bytes(C.byref(_lib.IvaeDims(1024, 5, 5, 0, 100, 3, 2, .1, 1)), C.byref(nb)) == 0 and nb.value > 0
+        finally:
+            for k in ("IVAE_AMD_TILE_ROWS", "IVAE_AMD_WAVES", "IVAE_AMD_WGRAD_ROWS"):
+                os.environ.pop(k, None)
 
 
 def _build(c):
