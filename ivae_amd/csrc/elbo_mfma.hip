@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * NW) void k_wgrad(Layout L, const float* __rest
 
     BwdCtx X;
     X.P = params + (size_t)model * L.n_params; X.wsm = wsm;
-    X.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.n_params;
+    X.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.slab_ld;
     X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = X.d1 = nullptr;
     const float* in_a = m == IVAE_MLP_F ? zrows : m == IVAE_MLP_LOGL ? um : xm;
     const int na = m == IVAE_MLP_F ? L.dl : m == IVAE_MLP_LOGL ? L.M : L.dd;
@@ -662,21 +662,27 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     }
 }
 
-// Thread t's share (rows t, t + NR, ...) of the sum over rows of the per-row ELBO terms.
-__device__ __forceinline__ float loss_partial(const Layout& L, const IvaeCoef& C, const float* wsm, int t) {
-    float acc = 0.f;
-    for (int i = t; i < L.B; i += NR) {
-        const float lpx = wsm[L.ws.lpx + i], lqc = wsm[L.ws.lqc + i], lp = wsm[L.ws.lp + i];
-        float row;
-        if (C.pairwise) {
-            const float lq = wsm[L.ws.lq + i], lqi = wsm[L.ws.lqi + i];
-            row = C.a * lpx - C.b * (lqc - lq) - C.c * (lq - lqi) - C.d * (lqi - lp);
-        } else {
-            row = C.a * lpx - C.b * lqc + C.d * lp;
-        }
-        acc += row;
+// Per-row ELBO term of row i.
+__device__ __forceinline__ float loss_row(const Layout& L, const IvaeCoef& C, const float* wsm, int i) {
+    const float lpx = wsm[L.ws.lpx + i], lqc = wsm[L.ws.lqc + i], lp = wsm[L.ws.lp + i];
+    if (C.pairwise) {
+        const float lq = wsm[L.ws.lq + i], lqi = wsm[L.ws.lqi + i];
+        return C.a * lpx - C.b * (lqc - lq) - C.c * (lq - lqi) - C.d * (lqi - lp);
     }
-    return acc;
+    return C.a * lpx - C.b * lqc + C.d * lp;
+}
+// Thread t's share (rows t, t + stride, ...) of the sum over rows of the per-row ELBO terms; four rows' loads in flight.
+__device__ __forceinline__ float loss_partial(const Layout& L, const IvaeCoef& C, const float* wsm, int t, int stride) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = t;
+    for (; i + 3 * stride < L.B; i += 4 * stride) {
+        a0 += loss_row(L, C, wsm, i);
+        a1 += loss_row(L, C, wsm, i + stride);
+        a2 += loss_row(L, C, wsm, i + 2 * stride);
+        a3 += loss_row(L, C, wsm, i + 3 * stride);
+    }
+    for (; i < L.B; i += stride) a0 += loss_row(L, C, wsm, i);
+    return (a0 + a1) + (a2 + a3);
 }
 
 // Encoder / prior backward.  blockIdx.z picks the MLP: 0 = g, 1 = logv, 2 = logl (three concurrent workgroups per row
@@ -739,7 +745,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
     // the per-row terms with k_reduce's thread map and order (same bits)
     if (loss_out && blockIdx.x == 0 && blockIdx.z == 0) {
         __syncthreads();
-        if (tid < NR) wbuf[tid] = loss_partial(L, C, wsm, tid);
+        if (tid < NR) wbuf[tid] = loss_partial(L, C, wsm, tid, NR);
         __syncthreads();
         for (int s = NR / 2; s > 0; s >>= 1) {
             if (tid < s) wbuf[tid] += wbuf[tid + s];
@@ -752,38 +758,49 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
 // Sum the per-tile slabs into grads and reduce the loss.  A block sums 64 parameters: wave g adds the tiles
 // t = g, g+4, ... with four independent accumulators (loads in flight), then the partials are combined in a fixed
 // order, so the result does not depend on scheduling.
-#define RED_P 64
-__global__ __launch_bounds__(NR) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
-                                               float* __restrict__ grads, float* __restrict__ loss_out) {
+#define RED_P 256
+#define RED_W 16          // waves of a k_reduce block: wave g sums the slabs g, g + 16, ...
+__global__ __launch_bounds__(64 * RED_W) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
+                                                       float* __restrict__ grads, float* __restrict__ loss_out) {
     const int model = blockIdx.y;
     const float* wsm = ws + (size_t)model * L.ws.per_model;
     const int nblk_p = L.n_wtiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;   // one tile: the kernels wrote grads directly
-    __shared__ float red[NR];
+    __shared__ f32x4 red4[64 * RED_W];
+    __shared__ float red[64 * RED_W];
     if ((int)blockIdx.x < nblk_p) {
-        const int p = min((int)blockIdx.x * RED_P + (int)(threadIdx.x & 63), L.n_params - 1);
-        const int g = threadIdx.x >> 6;
-        const float* s = wsm + L.ws_partial + p;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // a lane owns 4 consecutive parameters (slab rows are slab_ld = 4k floats apart and 16-byte aligned: one
+        // 128-bit load per slab, 1 KB contiguous per wave); 16 waves x 4 accumulators keep 64 slabs in flight per block
+        const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+        const int p4 = min((int)blockIdx.x * RED_P + 4 * l, L.slab_ld - 4);
+        const float* s = wsm + L.ws_partial + p4;
+        f32x4 a0 = ZERO4, a1 = ZERO4, a2 = ZERO4, a3 = ZERO4;
         int t = g;
-        for (; t + 12 < L.n_wtiles; t += 16) {
-            a0 += s[(size_t)t * L.n_params];
-            a1 += s[(size_t)(t + 4) * L.n_params];
-            a2 += s[(size_t)(t + 8) * L.n_params];
-            a3 += s[(size_t)(t + 12) * L.n_params];
+        for (; t + 3 * RED_W < L.n_wtiles; t += 4 * RED_W) {
+            a0 += *reinterpret_cast<const f32x4*>(s + (size_t)t * L.slab_ld);
+            a1 += *reinterpret_cast<const f32x4*>(s + (size_t)(t + RED_W) * L.slab_ld);
+            a2 += *reinterpret_cast<const f32x4*>(s + (size_t)(t + 2 * RED_W) * L.slab_ld);
+            a3 += *reinterpret_cast<const f32x4*>(s + (size_t)(t + 3 * RED_W) * L.slab_ld);
         }
-        for (; t < L.n_wtiles; t += 4) a0 += s[(size_t)t * L.n_params];
-        red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        for (; t < L.n_wtiles; t += RED_W) a0 += *reinterpret_cast<const f32x4*>(s + (size_t)t * L.slab_ld);
+        red4[threadIdx.x] = (a0 + a1) + (a2 + a3);
         __syncthreads();
-        if (g == 0 && (int)blockIdx.x * RED_P + (int)threadIdx.x < L.n_params)
-            grads[(size_t)model * L.n_params + p] = (red[threadIdx.x] + red[threadIdx.x + 64]) +
-                                                    (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        if (g == 0) {                            // fixed-order tree over the 16 waves
+            f32x4 q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                q[i] = (red4[l + 64 * (4 * i)] + red4[l + 64 * (4 * i + 1)]) + (red4[l + 64 * (4 * i + 2)] + red4[l + 64 * (4 * i + 3)]);
+            const f32x4 r = (q[0] + q[1]) + (q[2] + q[3]);
+            const int p0 = (int)blockIdx.x * RED_P + 4 * l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (p0 + e < L.n_params) grads[(size_t)model * L.n_params + p0 + e] = r[e];
+        }
         return;
     }
     if (!loss_out) return;
-    const float acc = loss_partial(L, C, wsm, threadIdx.x);
-    red[threadIdx.x] = acc;
+    red[threadIdx.x] = loss_partial(L, C, wsm, threadIdx.x, 64 * RED_W);
     __syncthreads();
-    for (int s = NR / 2; s > 0; s >>= 1) {
+    for (int s = 32 * RED_W; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
@@ -873,6 +890,6 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
     if ((e = launch_phase(L, C, 4, params, x, u, eps, nblk_p == 0 ? loss_out : nullptr, ws, grads, st)) != hipSuccess) return e;
     if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     if (nblk_p == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(NR), 0, st, L, C, ws, grads, loss_out);
+    hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out);
     return hipGetLastError();
 }

@@ -34,7 +34,8 @@ struct Layout {
     int maxh;            // widest row among hidden / output tensors
     // workspace (float offsets per model)
     IvaeWsLayout ws;
-    int64_t ws_partial;  // (n_wtiles, n_params) per-tile gradient slabs
+    int64_t ws_partial;  // (n_wtiles, slab_ld) per-tile gradient slabs (16-byte aligned rows)
+    int slab_ld;         // n_params rounded up to a multiple of 4
     int64_t ws_pair;     // scratch of the pairwise kernels for a (B, B, dl) problem
     // row tiling of k_fwd_enc / k_dec / k_bwd_enc (elbo_mfma.hip)
     int tr, n_tiles;     // rows per workgroup (16, 32 or 64), workgroups per model
@@ -173,7 +174,9 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
         L.smem_wg = smem(trw);
         L.n_wtiles = (L.B + trw - 1) / trw;
     }
-    L.ws_partial = take((int64_t)L.n_wtiles * L.n_params);
+    L.slab_ld = (L.n_params + 3) & ~3;
+    wso = (wso + 3) & ~(int64_t)3;
+    L.ws_partial = take((int64_t)L.n_wtiles * L.slab_ld);
     L.ws_dz = take(Bl);
     L.ws_pair = take((int64_t)ivae_pair_ws_floats(L.B, L.B, L.dl));
     wso = (wso + 63) & ~(int64_t)63;
