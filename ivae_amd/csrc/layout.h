@@ -128,9 +128,11 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     L.ws.lpx = take(L.B); L.ws.lqc = take(L.B); L.ws.lp = take(L.B); L.ws.lq = take(L.B); L.ws.lqi = take(L.B);
     L.ws.rz = take(Bl); L.ws.cg = take(Bl); L.ws.cv = take(Bl);
     L.ws.lse_s = take(L.B); L.ws.lse_k = take(Bl);
-    // rows per workgroup: the largest of 64/32/16 that still gives the 256 CUs a workgroup each and fits the LDS
-    int tr = 64;
-    while (tr > 16 && (int64_t)((L.B + tr - 1) / tr) * L.n_models < 256) tr >>= 1;
+    // rows per workgroup: 32 when that still gives every CU two row tiles, else 16 (measured: 64-row tiles lose to 32-row
+    // ones even on chip-filling launches -- their LDS footprint leaves one workgroup per CU and nothing to hide its
+    // chunk round trips behind; the knob below still selects them), subject to the LDS fit further down
+    int tr = 32;
+    while (tr > 16 && (int64_t)((L.B + tr - 1) / tr) * L.n_models < 512) tr >>= 1;
     if (const char* e = getenv("IVAE_AMD_TILE_ROWS")) {          // tuning knob: 16, 32 or 64
         const int v = atoi(e);
         if (v == 16 || v == 32 || v == 64) tr = v;
