@@ -359,11 +359,26 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
 
     for (int i = 4 * tid; i < L.smem_enc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(xin + i) = ZERO4;
     __syncthreads();
-    for (int idx = tid; idx < TR * (L.dd + L.M); idx += NT) {
-        const int r = idx / (L.dd + L.M), k = idx - r * (L.dd + L.M);
-        if (r < nrows) {
-            if (k < L.dd) xin[r * L.ldx + k] = xm[(size_t)r * L.dd + k];
-            else xin[r * L.ldx + L.uoff + (k - L.dd)] = um[(size_t)r * L.M + (k - L.dd)];
+    {   // input rows -> LDS: a wave per row, lanes over the columns, four loads in flight (no division, no load
+        // waited for one by one)
+        const int wv = tid >> 6, W = L.dd + L.M;
+        for (int r = wv; r < nrows; r += NW) {
+            const float* xr = xm + (size_t)r * L.dd;
+            const float* ur = um + (size_t)r * L.M - L.dd;          // indexed by k >= dd only (um is null when M == 0)
+            float* dst = xin + r * L.ldx;
+            for (int k0 = lane; k0 < W; k0 += 256) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + 64 * e;
+                    v[e] = k < L.dd ? xr[k] : k < W ? ur[k] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + 64 * e;
+                    if (k < W) dst[k < L.dd ? k : L.uoff + (k - L.dd)] = v[e];
+                }
+            }
         }
     }
     for (int r = tid; r < TR; r += NT) {
@@ -512,9 +527,21 @@ __global__ __launch_bounds__(64 * NW) void k_wgrad(Layout L, const float* __rest
     for (int i = 4 * tid; i < L.smem_wg / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dT + i) = ZERO4;
     __syncthreads();
     const float* dlt = wsm + D.dlt_off[li] + row0;
-    for (int idx = tid; idx < N * TR; idx += NT) {
-        const int n = idx / TR, r = idx - n * TR;
-        if (r < nrows) dT[n * L.ldr + r] = dlt[(size_t)n * L.Bp + r];
+    {   // (TR is a power of two; four loads in flight)
+        const int sh = __ffs(TR) - 1, tot = N * TR;
+        for (int i0 = tid; i0 < tot; i0 += 4 * NT) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = i0 + e * NT, n = idx >> sh, r = idx & (TR - 1);
+                v[e] = (idx < tot && r < nrows) ? dlt[(size_t)n * L.Bp + r] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = i0 + e * NT, n = idx >> sh, r = idx & (TR - 1);
+                if (idx < tot) dT[n * L.ldr + r] = v[e];
+            }
+        }
     }
     // (the first tile_gemm's barrier orders these writes before any operand read)
     float* gW = X.slab + D.w_off[li];
