@@ -1,12 +1,12 @@
 // Shape-generic ELBO forward / backward kernels on the fp32 matrix cores (any dims, activation, depth).
 //
-// One 256-thread workgroup (4 waves) owns a tile of TR = 16/32/64 batch rows of one model.  Every layer product
-// (forward, input gradient, weight gradient) is the same "row-row" contraction
+// One workgroup of NW = 4 / 8 / 16 waves owns a tile of TR = 16/32/64 batch rows of one model (k_wgrad: 16 .. 256 rows).
+// Every layer product (forward, input gradient, weight gradient) is the same "row-row" contraction
 //
 //        out[i][j] = sum_k  A[i][k] * Bm[j][k]          (v_mfma_f32_16x16x4_f32, exact fp32 FMA chain)
 //
 // with A resident in LDS (activation / delta tiles, row stride 4*odd floats so that 128-bit operand reads spread
-// over the banks) and Bm streamed through LDS in 64 x 64 chunks:
+// over the banks) and Bm streamed through LDS in chunks of 16 NW output columns x 64 contraction steps:
 //   forward      A = layer input  [row][k]      Bm = W[n][k]  (+ bias as column K: inputs carry a constant-1 column)
 //   dgrad        A = delta        [row][n]      Bm = W^T[k][n]
 //   wgrad        A = delta^T      [n][row]      Bm = input^T[k][row]  (+ a row of ones: bias gradient)
@@ -15,8 +15,11 @@
 // are issued one chunk ahead into registers (also across layer boundaries), so the L2 latency of the weights hides
 // behind the previous chunk's MFMAs.  Hidden activations and their derivatives go to the caller's workspace feature-major
 // ((H, Bp), Bp = batch rounded up to 64) so that the backward pass reads them as transposed operands directly.
-// Weight gradients are written as per-tile slabs and summed in a fixed order by k_reduce: results are bitwise
-// reproducible run to run (no float atomics).
+// The step is split by data dependency: k_fwd_enc (three MLP chains as concurrent workgroups), k_dec (decoder forward,
+// row log-densities, decoder input-gradient chain), k_bwd_enc (head deltas + input-gradient chains), then k_wgrad --
+// nothing on the dependent chain of layers waits for a weight gradient, so every layer's is its own workgroup, fed by
+// the layer deltas the chains left in the workspace.  Weight gradients are written as per-tile slabs and summed in a
+// fixed order by k_reduce: results are bitwise reproducible run to run (no float atomics).
 //
 // Reference arithmetic restated here: models/nets.py:114-121 (MLP.forward), 301-314 (Normal.sample / log_pdf),
 // 45-52 (log_normal), 450-475, 587-599, 165-185, 224-243 (forward / elbo of the four model classes); backward =
@@ -25,7 +28,7 @@
 #include "layout.h"
 #include "kernels.h"
 
-#define NR 256            // threads of a k_reduce block
+#define NR 256            // threads of a loss reduction
 #define KCH 64            // contraction extent of a staged chunk
 #define LDC 68            // chunk row stride (4 * odd)
 // Geometry of a workgroup of NW waves (4, 8 or 16): NT threads, chunks of NCH = 16 NW rows (output columns) x KCH
