@@ -748,26 +748,41 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
     chunk_load<NW>(St, L.L > 1 ? dgrad_src(X, L.mlp[m], L.L - 1) : src_none(), 0, 0);
     for (int i = 4 * tid; i < L.smem_benc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dA + i) = ZERO4;
     __syncthreads();
-    for (int idx = tid; idx < nrows * L.dl; idx += NT) {
-        const int r = idx / L.dl, k = idx - r * L.dl;
-        const size_t o = (size_t)(row0 + r) * L.dl + k;
-        const float zz = wsm[L.ws.z + o], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o], ll = wsm[L.ws.l + o];
-        const float dq = zz - gg;
-        const float rr = dq / vv;
-        float Gz = wsm[L.ws_dz + o] - w * (C.b * rr - C.d * zz / ll);
-        if (C.pairwise) Gz -= w * wsm[L.ws.rz + o];
-        float dlt;
-        if (mi == 0) {
-            dlt = w * C.b * rr + Gz;
-            if (C.pairwise) dlt -= w * wsm[L.ws.cg + o];
-        } else if (mi == 1) {
-            dlt = -w * C.b * 0.5f * (1.f - dq * dq / vv) + Gz * 0.5f * em[(size_t)r * L.dl + k] * sqrtf(vv);
-            if (C.pairwise) dlt -= w * wsm[L.ws.cv + o];
-        } else {
-            dlt = w * C.d * 0.5f * (1.f - zz * zz / ll);
+    {   // head deltas: element idx = r * dl + k of the tile sits at (row0 * dl + idx) in every (B, dl) workspace tensor, so
+        // the loads need no division; two elements per pass keep both elements' loads in flight
+        const int tot = nrows * L.dl;
+        const size_t ob = (size_t)row0 * L.dl;
+        auto head_delta = [&](int idx) -> float {
+            const size_t o = ob + idx;
+            const float zz = wsm[L.ws.z + o], gg = wsm[L.ws.g + o], vv = wsm[L.ws.v + o], ll = wsm[L.ws.l + o];
+            const float dq = zz - gg;
+            const float rr = dq / vv;
+            float Gz = wsm[L.ws_dz + o] - w * (C.b * rr - C.d * zz / ll);
+            if (C.pairwise) Gz -= w * wsm[L.ws.rz + o];
+            float dlt;
+            if (mi == 0) {
+                dlt = w * C.b * rr + Gz;
+                if (C.pairwise) dlt -= w * wsm[L.ws.cg + o];
+            } else if (mi == 1) {
+                dlt = -w * C.b * 0.5f * (1.f - dq * dq / vv) + Gz * 0.5f * em[idx] * sqrtf(vv);
+                if (C.pairwise) dlt -= w * wsm[L.ws.cv + o];
+            } else {
+                dlt = w * C.d * 0.5f * (1.f - zz * zz / ll);
+            }
+            return dlt;
+        };
+        auto put = [&](int idx, float dlt) {
+            const int r = idx / L.dl, k = idx - r * L.dl;
+            dA[r * L.ldd + k] = dlt;
+            dltT[(size_t)k * L.Bp + r] = dlt;
+        };
+        for (int i0 = tid; i0 < tot; i0 += 2 * NT) {
+            const int i1 = i0 + NT;
+            const float d0 = head_delta(i0);
+            const float d1 = head_delta(min(i1, tot - 1));
+            put(i0, d0);
+            if (i1 < tot) put(i1, d1);
         }
-        dA[r * L.ldd + k] = dlt;
-        dltT[(size_t)k * L.Bp + r] = dlt;
     }
     mlp_bwd<RTE, NW>(L, X, L.mlp[m], nullptr, 0, src_none(), St);
     MSTAMP(202);
