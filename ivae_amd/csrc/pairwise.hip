@@ -154,12 +154,29 @@ __global__ __launch_bounds__(PB) void k_pair_combine(PairGeom P, const float* __
     const size_t plane = (size_t)(P.d + 1) * P.n_rows, at = (size_t)k * P.n_rows + i;
     const float* pm = ws + P.o_pm + at;
     const float* ps = ws + P.o_ps + at;
+    // 16 slices at a time, their loads in flight together (one memory round trip per group instead of one per unrolled
+    // batch of 8); same arithmetic and order as a plain loop over the slices: global max first, then the sum
     float M = NEG_BIG;
-#pragma unroll 8
-    for (int sl = 0; sl < P.NS; ++sl) M = fmaxf(M, pm[sl * plane]);
+    for (int s0 = 0; s0 < P.NS; s0 += 16) {
+        float m16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m16[e] = pm[min(s0 + e, P.NS - 1) * plane];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) M = fmaxf(M, m16[e]);          // (a clamped repeat of the last slice changes nothing)
+    }
     float s = 0.f;
-#pragma unroll 8
-    for (int sl = 0; sl < P.NS; ++sl) s += ps[sl * plane] * exp2f(pm[sl * plane] - M);
+    for (int s0 = 0; s0 < P.NS; s0 += 16) {
+        float m16[16], p16[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int sl = min(s0 + e, P.NS - 1);
+            m16[e] = pm[sl * plane];
+            p16[e] = ps[sl * plane];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (s0 + e < P.NS) s += p16[e] * exp2f(m16[e] - M);
+    }
     const float lse = M * LN2 + logf(s);
     if (k == P.d) lse_s[i] = lse;
     else lse_k[(size_t)i * P.d + k] = lse;
