@@ -173,25 +173,27 @@ __global__ __launch_bounds__(256) void k_corr_batched(const float* __restrict__ 
 }
 
 hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int d, double* cc, hipStream_t st) {
+    static SmemCache cur = {};
     const size_t smem = sizeof(double) * ((size_t)CORR_ROWS * (2 * d + 1) + 2 * d + (size_t)d * d + 2 * d + 256);
-    if (smem > 64 * 1024) {      // d > ~40: above the default dynamic-LDS limit (rare; the attribute call is cheap)
-        hipError_t e = hipFuncSetAttribute((const void*)k_corr_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-    }
+    hipError_t e = set_smem((const void*)k_corr_batched, (int)smem, cur);      // d > ~40: above the default dynamic-LDS limit
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_corr_batched, dim3((unsigned)n_blocks), dim3(256), smem, st, x, y, n, d, cc);
     return hipGetLastError();
 }
 
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st) {
+    static SmemCache cur = {};
     double* mean = ws;
     double* psum = mean + 2 * d;
     double* pmom = psum + (size_t)CORR_BLOCKS * 2 * d;
     int nblk = (int)((n + CORR_ROWS - 1) / CORR_ROWS);
     if (nblk > CORR_BLOCKS) nblk = CORR_BLOCKS;
+    const size_t smem = (size_t)CORR_ROWS * (2 * d + 1) * sizeof(double);          // d = 64: 66048 B, above the default limit
+    hipError_t e = set_smem((const void*)k_corr_moments, (int)smem, cur);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_corr_sums, dim3(nblk), dim3(256), 0, st, x, y, n, d, psum);
     hipLaunchKernelGGL(k_corr_mean, dim3(1), dim3(128), 0, st, psum, n, d, nblk, mean);
-    hipLaunchKernelGGL(k_corr_moments, dim3(nblk), dim3(256), (size_t)CORR_ROWS * (2 * d + 1) * sizeof(double), st, x, y,
-                       n, d, mean, pmom);
+    hipLaunchKernelGGL(k_corr_moments, dim3(nblk), dim3(256), smem, st, x, y, n, d, mean, pmom);
     hipLaunchKernelGGL(k_corr_final, dim3(1), dim3(256), (size_t)(d * d + 2 * d) * sizeof(double), st, pmom, n, d, nblk, cc);
     return hipGetLastError();
 }

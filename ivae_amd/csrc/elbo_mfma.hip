@@ -853,23 +853,6 @@ __global__ __launch_bounds__(64 * RED_W) void k_reduce(Layout L, IvaeCoef C, con
 }
 
 // ------------------------------------------------------------------------------ launchers
-// Dynamic LDS above 64 KB needs the function attribute; it is raised only when a launch needs more than what this
-// process has already asked for ON THE CURRENT DEVICE (the attribute is per device; the cache is a plain array of
-// monotonically growing values, so a race between host threads only costs a redundant call).
-#define MAX_DEVICES 64
-struct SmemCache { int v[MAX_DEVICES]; };
-static hipError_t set_smem(const void* fn, int bytes, SmemCache& cache) {
-    if (bytes <= 64 * 1024) return hipSuccess;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const bool cached = dev >= 0 && dev < MAX_DEVICES;
-    if (cached && bytes <= cache.v[dev]) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess && cached) cache.v[dev] = bytes;
-    return e;
-}
-
 template <int RTE, int NW>
 static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
                            const float* eps, float* z_out, float* ws, float* grads, hipStream_t st) {

@@ -1032,13 +1032,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
 // ------------------------------------------------------------------------------ host side
 template <class C>
 static hipError_t launch_cfg(const FusedArgs& A, int n_models, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_train_steps<C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)C::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static SmemCache cur = {};      // per device: a process may drive this entry point on several GPUs
+    hipError_t e = set_smem((const void*)k_train_steps<C>, (int)C::LDS_BYTES, cur);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_train_steps<C>, dim3(n_models), dim3(FT_THREADS), C::LDS_BYTES, st, A);
     return hipGetLastError();
 }

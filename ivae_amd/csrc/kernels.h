@@ -16,3 +16,20 @@ hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, 
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st);
 size_t corr_ws_bytes(int64_t n, int d);
 hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int d, double* cc, hipStream_t st);
+
+// Dynamic LDS above 64 KB needs the function attribute; it is raised only when a launch needs more than what this
+// process has already asked for ON THE CURRENT DEVICE (the attribute is per device; the cache is a plain array of
+// monotonically growing values, so a race between host threads only costs a redundant call).
+#define IVAE_MAX_DEVICES 64
+struct SmemCache { int v[IVAE_MAX_DEVICES]; };
+static inline hipError_t set_smem(const void* fn, int bytes, SmemCache& cache) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool cached = dev >= 0 && dev < IVAE_MAX_DEVICES;
+    if (cached && bytes <= cache.v[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && cached) cache.v[dev] = bytes;
+    return e;
+}
