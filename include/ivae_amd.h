@@ -189,6 +189,17 @@ int ivae_corr_workspace_bytes(int64_t n, int32_t d, size_t* out);
 int ivae_corr(const float* x, const float* y, int64_t n, int32_t d, double* cc_out,
               void* workspace, size_t workspace_bytes, void* stream);
 
+/* ivae_corr without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  The scratch ivae_corr takes as `workspace` lives in a fixed array inside the library instead
+ * (3,605,120 bytes per GPU, held until the process ends), which bounds the problem: d <= IVAE_CORR_STATIC_MAX_D (any n).
+ * Larger d returns IVAE_E_TOOLARGE (ivae_last_hip_error() names the limit); use ivae_corr there.  Same kernels, same
+ * arithmetic and summation order as ivae_corr: results are bit-identical.  The device that `stream` belongs to must be
+ * current.  All calls on one GPU share that GPU's array: two calls that overlap on one GPU (different streams or host
+ * threads without ordering between them) race; calls ordered on one stream are fine. */
+#define IVAE_CORR_STATIC_MAX_D 40
+int ivae_corr_static(const float* x, const float* y, int64_t n, int32_t d, double* cc_out, void* stream);
+
 /* The same correlation block for n_blocks independent (n, d) problems stored back to back -- the per-step batch
  * scores of a training epoch (runners/ivae.py:86, models/wrappers.py:75 call mcc once per step on the batch):
  * x, y (n_blocks, n, d) fp32; cc_out (n_blocks, d, d) float64.  One launch, no workspace. */

@@ -36,7 +36,7 @@ class IvaeWsLayout(C.Structure):
 
 
 EXPORTS = ["ivae_param_count", "ivae_workspace_bytes", "ivae_workspace_layout", "ivae_elbo_fwd_bwd", "ivae_forward",
-           "ivae_pairwise", "ivae_pairwise_workspace_bytes", "ivae_backward", "ivae_adam_step", "ivae_elbo_adam_steps", "ivae_train_steps", "ivae_train_steps_supported", "ivae_corr_workspace_bytes", "ivae_corr", "ivae_corr_batched",
+           "ivae_pairwise", "ivae_pairwise_workspace_bytes", "ivae_backward", "ivae_adam_step", "ivae_elbo_adam_steps", "ivae_train_steps", "ivae_train_steps_supported", "ivae_corr_workspace_bytes", "ivae_corr", "ivae_corr_static", "ivae_corr_batched",
            "ivae_last_hip_error", "ivae_version"]
 
 _lib = None
@@ -68,6 +68,7 @@ def lib():
                                    f64, f64, f64, f64, vp, vp, vp, vp]
     L.ivae_corr_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_size_t)]
     L.ivae_corr.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_size_t, vp]
+    L.ivae_corr_static.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp]
     L.ivae_corr_batched.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int32, vp, vp]
     L.ivae_last_hip_error.restype = C.c_char_p
     L.ivae_version.restype = C.c_char_p

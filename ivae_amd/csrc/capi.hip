@@ -218,6 +218,18 @@ int ivae_corr(const float* x, const float* y, int64_t n, int32_t d, double* cc_o
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_corr");
 }
 
+int ivae_corr_static(const float* x, const float* y, int64_t n, int32_t d, double* cc_out, void* stream) {
+    if (!x || !y || !cc_out) return IVAE_E_NULLPTR;
+    if (n < 2 || d <= 0) return IVAE_E_BADDIMS;
+    if (d > CORR_STATIC_MAX_D) {
+        snprintf(g_err, sizeof(g_err), "ivae_corr_static: d = %d exceeds the built-in scratch (d <= %d); use ivae_corr", (int)d,
+                 CORR_STATIC_MAX_D);
+        return IVAE_E_TOOLARGE;
+    }
+    hipError_t e = launch_corr_static(x, y, n, d, cc_out, (hipStream_t)stream);
+    return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_corr_static");
+}
+
 int ivae_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int32_t d, double* cc_out,
                       void* stream) {
     if (!x || !y || !cc_out) return IVAE_E_NULLPTR;

@@ -197,3 +197,31 @@ hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double*
     hipLaunchKernelGGL(k_corr_final, dim3(1), dim3(256), (size_t)(d * d + 2 * d) * sizeof(double), st, pmom, n, d, nblk, cc);
     return hipGetLastError();
 }
+
+// ---- the same computation with the scratch inside the library: ivae_corr_static (callers that cannot allocate) ----
+// `scratch` holds what ivae_corr's workspace argument holds (column means, per-block column sums, per-block centred
+// moments) for d <= CORR_STATIC_MAX_D.  In host code the array's NAME is only a stand-in: the address the kernels get is
+// the one hipGetSymbolAddress returns for the CURRENT device (every GPU holds its own copy), looked up once per device
+// and kept in scratch_ptr[].  Nothing here must start at zero: every word a kernel reads was written by the kernel
+// before it in the same call (blocks 0..nblk-1 only), so a call does not depend on what the last one left.
+#define CORR_STATIC_DOUBLES (2 * CORR_STATIC_MAX_D + CORR_BLOCKS * 2 * CORR_STATIC_MAX_D + \
+                             CORR_BLOCKS * (CORR_STATIC_MAX_D * CORR_STATIC_MAX_D + 2 * CORR_STATIC_MAX_D))
+static __device__ __align__(256) double scratch[CORR_STATIC_DOUBLES];      // 3,605,120 B per GPU
+
+static double* scratch_ptr[IVAE_MAX_DEVICES];       // per device; written once (racing host threads write the same value)
+
+hipError_t launch_corr_static(const float* x, const float* y, int64_t n, int d, double* cc, hipStream_t st) {
+    if (d > CORR_STATIC_MAX_D || corr_ws_bytes(n, d) > sizeof(double) * (size_t)CORR_STATIC_DOUBLES) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= IVAE_MAX_DEVICES) return hipErrorInvalidDevice;
+    double* ptr = __atomic_load_n(&scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!ptr) {
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        __atomic_store_n(&scratch_ptr[dev], ptr, __ATOMIC_RELEASE);
+    }
+    return launch_corr(x, y, n, d, cc, ptr, st);
+}

@@ -16,6 +16,8 @@ hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, 
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st);
 size_t corr_ws_bytes(int64_t n, int d);
 hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int d, double* cc, hipStream_t st);
+hipError_t launch_corr_static(const float* x, const float* y, int64_t n, int d, double* cc, hipStream_t st);
+#define CORR_STATIC_MAX_D 40
 
 // Dynamic LDS above 64 KB needs the function attribute; it is raised only when a launch needs more than what this
 // process has already asked for ON THE CURRENT DEVICE (the attribute is per device; the cache is a plain array of
