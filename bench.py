@@ -66,16 +66,18 @@ def flops_per_sample(shape):
 
 def measured_traffic(kernel, models, steps_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/hbm_traffic.json:
-    FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command); None when this run's launch
-    geometry differs from the profiled one."""
+    FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc runs of this same command at two launch lengths).  A launch moves
+    a fixed part (parameters and Adam moments in and out, once) plus a per-step part (the gathered batch rows), both
+    proportional to the number of packed models, so the figure for this run's geometry is
+    models/256 * (fixed + per_step * steps_per_launch)."""
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             t = json.load(f)
     except OSError:
         return None
-    if t["kernel"] != kernel or t["models_per_gpu"] != models or t["steps_per_launch"] != steps_per_launch:
+    if t.get("kernel") != kernel or "fixed_kb_per_launch" not in t:
         return None
-    return 1e3 * (t["fetch_kb_per_launch"] + t["write_kb_per_launch"])
+    return round(1e3 * models / t["models_per_gpu"] * (t["fixed_kb_per_launch"] + t["kb_per_step"] * steps_per_launch), 1)
 
 
 def cpu_baseline(seconds=10.0):
@@ -89,7 +91,8 @@ def cpu_baseline(seconds=10.0):
     x = torch.randn(N, 10, generator=g)
     u = torch.zeros(N, 40)
     u[torch.arange(N), torch.arange(N) // 1000] = 1
-    avail = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    host = len(os.sched_getaffinity(0))
+    avail = int(os.environ.get("OMP_NUM_THREADS", "0")) or host
     results = {}
     for nt in sorted({1, min(avail, 16)}):
         torch.set_num_threads(nt)
@@ -106,10 +109,79 @@ def cpu_baseline(seconds=10.0):
                 steps += 1
         results[nt] = steps * B / (time.perf_counter() - t0)
     best = max(results, key=results.get)
-    return {"value": round(results[best], 1), "unit": "samples/s", "cores": best, "kind": "port",
+    return {"value": round(results[best], 1), "unit": "samples/s", "cores": best, "host_cores": host,
+            "threads_allotted": avail, "by_threads": {str(k): round(v, 1) for k, v in results.items()}, "kind": "port",
             "sample": "cfg2 iVAE d=10 M=40 H=50 B=64 single model, oracle/torch_ref.Trainer (torch CPU elbo+backward+"
                       "Adam), ~%.0f s per thread setting; by threads: %s" % (
                           seconds / 2, {k: round(v) for k, v in results.items()})}
+
+
+# ---- the other BASELINE configs on the shape-generic kernels (one model each; extra keys of the JSON line) ----------
+OTHER_CONFIGS = [
+    # key, workload, (data, latent, aux, hidden, act), batch, loss weights, N
+    ("configs[0]", "configs/ivae.yaml: cleanIVAE d=5 M=40 H=100 xtanh, batch 64, TC-decomposed loss (pairwise B x B x d terms)",
+     (5, 5, 40, 100, "xtanh"), 64, dict(a=100., b=1., c=0., d=10., pairwise=True, decoder_var=.1), 40000),
+    ("configs[2]", "configs/btcvae.yaml: cleanVAE d=5 H=100 xtanh, batch 1024, beta-TCVAE weights (pairwise terms)",
+     (5, 5, 0, 100, "xtanh"), 1024, dict(a=1000., b=1., c=15., d=1., pairwise=True, decoder_var=.1), 40000),
+    ("configs[3]", "large-batch iVAE d=20 M=200 H=50 lrelu, batch 4096, plain ELBO (one GPU's view of the DP run)",
+     (20, 20, 200, 50, "lrelu"), 4096, dict(pairwise=False), 1000000),
+]
+
+
+def other_config_lines(dev, steps=200):
+    """fwd+bwd[+pairwise]+Adam through ivae_elbo_adam_steps (one library call for all steps), HIP events on the launch
+    stream around the call; FLOPs per SURVEY.md §8(d): MLP part + 2.5 * 8 * B * d per sample for the pairwise terms."""
+    from ivae_amd import ops
+    out = []
+    for key, workload, (dd, dl, M, H, act), B, ck, N in OTHER_CONFIGS:
+        shape = ops.ModelShape(dd, dl, M, H, 3, act, .1)
+        g = torch.Generator(device=dev).manual_seed(0)
+        P = shape.n_params()
+        params = (torch.rand(P, generator=g, device=dev) - .5) * .2
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        xs = torch.randn(steps, B, dd, generator=g, device=dev)
+        us = None
+        if M:
+            us = torch.zeros(steps * B, M, device=dev)
+            us[torch.arange(steps * B, device=dev), torch.randint(0, M, (steps * B,), generator=g, device=dev)] = 1
+            us = us.view(steps, B, M)
+        eps = torch.randn(steps, B, dl, generator=g, device=dev)
+        coef = ops.make_coef(N=N, global_batch=B, **ck)
+        ws = ops.Workspace()
+        z = torch.empty_like(eps)
+        ops.elbo_adam_steps(shape, coef, params, m, v, xs[:20], None if us is None else us[:20], eps[:20], ws, 0, 1e-3,
+                            z_out=z[:20])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        loss, _ = ops.elbo_adam_steps(shape, coef, params, m, v, xs, us, eps, ws, 20, 1e-3, z_out=z)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = 1e-3 * e0.elapsed_time(e1) / steps
+        fl = flops_per_sample(shape) + (int(2.5 * 8 * B * dl) if ck.get("pairwise") else 0)
+        tf = fl * B / dt / 1e12
+        assert bool(torch.isfinite(loss).all()), key
+        out.append({"config": key, "workload": workload, "impl": "shape-generic kernels, one model", "value": round(B / dt, 1),
+                    "unit": "samples/s", "ms_per_step": round(1e3 * dt, 5), "steps": steps,
+                    "roofline": {"bound": "mfma", "achieved": round(tf, 4), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(tf / FP32_PEAK_TFLOPS, 5), "algorithmic_flops_per_sample": fl}})
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run as a CHILD
+    process, before this process touches the GPU) and leave with its exit code."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime
+    if n > have:
+        sys.exit("bench.py: --gpus %d asked for, %d GPU(s) visible; refusing to report a smaller run as N=%d" % (n, have, n))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
@@ -120,12 +192,20 @@ def main():
     ap.add_argument("--models", type=int, default=256, help="independent models packed per GPU")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--impl", choices=["fused", "generic"], default="fused")
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="fused path: steps per k_train_steps launch (default 125)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
 
+    ap.add_argument("--no-other-configs", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -141,6 +221,8 @@ def main():
     fused = args.impl == "fused"
     if fused:
         tr = FusedPackedTrainer(shape, n_models=M, batch=B, lr=1e-2, seed=rank, device=dev)
+        if args.steps_per_launch > 0:
+            tr.CHUNK = args.steps_per_launch
     else:
         tr = PackedTrainer(shape, n_models=M, batch=B, lr=1e-2, seed=rank, device=dev)
     tr.set_data(x, u)
@@ -197,6 +279,8 @@ def main():
                          "avg_launch_us": round(kern_s * 1e6, 2),
                          "steps_per_launch": steps_per_launch, "algorithmic_flops_per_launch": algo_flops},
         }
+        if world == 1 and not args.no_other_configs:
+            out["other_configs"] = other_config_lines(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

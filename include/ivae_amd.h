@@ -51,6 +51,12 @@ typedef struct IvaeDims {
     int32_t activation;   /* IVAE_ACT_* (models/nets.py:86-97) */
     float   slope;        /* lrelu negative slope / xtanh linear term */
     int32_t n_models;     /* >= 1 */
+    /* Tuning of the shape-generic kernels; 0 = the library picks from the launch geometry.  They are part
+     * of the shape because they decide the workspace layout: pass the SAME values to the size query and to the calls.
+     * Every combination meets the same parity bar (tests/test_gpu_parity.py). */
+    int32_t tile_rows;    /* 0 | 16 | 32 | 64: batch rows per workgroup */
+    int32_t waves;        /* 0 | 4 | 8 | 16: waves per workgroup (a streamed operand chunk holds 16*waves columns) */
+    int32_t wgrad_rows;   /* 0 | 16 | 32 | 64 | 128 | 256: batch rows per weight-gradient workgroup (sets the slab count) */
 } IvaeDims;
 
 /* Loss definition.  loss = -(1/Bg) * sum_i [ a*lpx - b*(lqc-lq) - c*(lq-lqi) - d*(lqi-lp) ]
@@ -79,10 +85,14 @@ typedef struct IvaeWsLayout {
 /* Number of fp32 parameters of one model (sum over nn.Linear layers). */
 int ivae_param_count(const IvaeDims* dims, int64_t* out);
 
-/* Bytes of caller-provided scratch the calls below need for `dims` (all models). */
-int ivae_workspace_bytes(const IvaeDims* dims, size_t* out);
+/* Bytes of caller-provided scratch the calls below need for `dims` (all models) when they are given a coef with this
+ * `pairwise` flag.  pairwise = 0: linear in the batch.  pairwise != 0: plus the pairwise kernels' scratch for a
+ * (batch, batch, latent_dim) problem, which grows roughly as batch^2 * latent_dim / 341 -- so query with 0 for plain
+ * calls (a full-dataset ivae_forward).  A workspace sized with pairwise != 0 also serves pairwise = 0 calls. */
+int ivae_workspace_bytes(const IvaeDims* dims, int32_t pairwise, size_t* out);
 
-int ivae_workspace_layout(const IvaeDims* dims, IvaeWsLayout* out);
+/* Row-tensor offsets for the same (dims, pairwise); only per_model depends on `pairwise`. */
+int ivae_workspace_layout(const IvaeDims* dims, int32_t pairwise, IvaeWsLayout* out);
 
 /* ---- ELBO forward + backward ---------------------------------------------------------
  * Replaces  model.elbo(x,u[,N,a,b,c,d]) -> loss.backward()

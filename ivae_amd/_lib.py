@@ -21,7 +21,7 @@ ERRORS = {
 class IvaeDims(C.Structure):
     _fields_ = [("batch", C.c_int32), ("data_dim", C.c_int32), ("latent_dim", C.c_int32), ("aux_dim", C.c_int32),
                 ("hidden_dim", C.c_int32), ("n_layers", C.c_int32), ("activation", C.c_int32), ("slope", C.c_float),
-                ("n_models", C.c_int32)]
+                ("n_models", C.c_int32), ("tile_rows", C.c_int32), ("waves", C.c_int32), ("wgrad_rows", C.c_int32)]
 
 
 class IvaeCoef(C.Structure):
@@ -53,8 +53,8 @@ def lib():
     vp, f64 = C.c_void_p, C.c_double
     pd, pc = C.POINTER(IvaeDims), C.POINTER(IvaeCoef)
     L.ivae_param_count.argtypes = [pd, C.POINTER(C.c_int64)]
-    L.ivae_workspace_bytes.argtypes = [pd, C.POINTER(C.c_size_t)]
-    L.ivae_workspace_layout.argtypes = [pd, C.POINTER(IvaeWsLayout)]
+    L.ivae_workspace_bytes.argtypes = [pd, C.c_int32, C.POINTER(C.c_size_t)]
+    L.ivae_workspace_layout.argtypes = [pd, C.c_int32, C.POINTER(IvaeWsLayout)]
     L.ivae_elbo_fwd_bwd.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_forward.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_pairwise_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]

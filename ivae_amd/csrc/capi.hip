@@ -23,25 +23,25 @@ const char* ivae_version(void) { return "ivae_amd 0.1 (gfx950)"; }
 int ivae_param_count(const IvaeDims* dims, int64_t* out) {
     if (!out) return IVAE_E_NULLPTR;
     Layout L;
-    int rc = ivae_make_layout(dims, &L);
+    int rc = ivae_make_layout(dims, false, &L);
     if (rc) return rc;
     *out = L.n_params;
     return IVAE_OK;
 }
 
-int ivae_workspace_bytes(const IvaeDims* dims, size_t* out) {
+int ivae_workspace_bytes(const IvaeDims* dims, int32_t pairwise, size_t* out) {
     if (!out) return IVAE_E_NULLPTR;
     Layout L;
-    int rc = ivae_make_layout(dims, &L);
+    int rc = ivae_make_layout(dims, pairwise != 0, &L);
     if (rc) return rc;
     *out = (size_t)L.ws.per_model * L.n_models * sizeof(float);
     return IVAE_OK;
 }
 
-int ivae_workspace_layout(const IvaeDims* dims, IvaeWsLayout* out) {
+int ivae_workspace_layout(const IvaeDims* dims, int32_t pairwise, IvaeWsLayout* out) {
     if (!out) return IVAE_E_NULLPTR;
     Layout L;
-    int rc = ivae_make_layout(dims, &L);
+    int rc = ivae_make_layout(dims, pairwise != 0, &L);
     if (rc) return rc;
     *out = L.ws;
     return IVAE_OK;
@@ -57,7 +57,8 @@ static int check_coef(const IvaeDims* dims, const IvaeCoef* c) {
 int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
                  const float* eps, float* z_out, void* workspace, size_t workspace_bytes, void* stream) {
     Layout L;
-    int rc = ivae_make_layout(dims, &L);
+    if (!coef) return IVAE_E_NULLPTR;
+    int rc = ivae_make_layout(dims, coef->pairwise != 0, &L);
     if (rc) return rc;
     if ((rc = check_coef(dims, coef))) return rc;
     if (!params || !x || !eps || !z_out || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
@@ -93,7 +94,8 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
                   const float* eps, float* loss_out, float* grads, void* workspace, size_t workspace_bytes,
                   void* stream) {
     Layout L;
-    int rc = ivae_make_layout(dims, &L);
+    if (!coef) return IVAE_E_NULLPTR;
+    int rc = ivae_make_layout(dims, coef->pairwise != 0, &L);
     if (rc) return rc;
     if ((rc = check_coef(dims, coef))) return rc;
     if (!params || !x || !eps || !grads || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
@@ -106,7 +108,8 @@ int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* p
                       const float* eps, float* z_out, float* loss_out, float* grads, void* workspace,
                       size_t workspace_bytes, void* stream) {
     Layout L;
-    int rc = ivae_make_layout(dims, &L);
+    if (!coef) return IVAE_E_NULLPTR;
+    int rc = ivae_make_layout(dims, coef->pairwise != 0, &L);
     if (rc) return rc;
     if ((rc = check_coef(dims, coef))) return rc;
     if (!params || !x || !eps || !z_out || !grads || !workspace || (L.M > 0 && !u)) return IVAE_E_NULLPTR;
@@ -177,6 +180,7 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, 
     if (!params || !exp_avg || !exp_avg_sq || !x_data || !batch_idx || !loss_out || (dims->aux_dim > 0 && !u_data))
         return IVAE_E_NULLPTR;
     if (n_steps <= 0 || n_data <= 0 || step0 < 0) return IVAE_E_BADDIMS;
+    if (n_data > 0x7fffffff) return IVAE_E_TOOLARGE;          // row indices are int32
     FusedArgs A;
     A.params = params; A.exp_avg = exp_avg; A.exp_avg_sq = exp_avg_sq;
     A.x_data = x_data; A.u_data = u_data; A.batch_idx = batch_idx; A.eps = eps;

@@ -743,7 +743,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
 #endif
     const float w1 = A.w1, b2 = A.beta2, w2 = A.w2, aeps = A.adam_eps;
     float xu[C::NXU];
-    load_xu<C>(xu, idxp[tid >> 3], xd, ud);
+    // row indices are clamped to the dataset: a bad index reads a wrong (valid) row instead of faulting the GPU
+    const int last_row = (int)(A.n_data - 1);
+    load_xu<C>(xu, min(max(idxp[tid >> 3], 0), last_row), xd, ud);
     float neg_step = 0.f, inv_bc2 = 1.f;       // of the previous step (its last layer's Adam runs in P0)
 
 // Weight-gradient product of one layer with Adam of another layer (LA, gradient in stage_a) issued between its MFMAs.
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         }
         // row index of the next step's batch (the last step re-reads its own: unconditional, so that the wait-count
         // pass never sees a load that is pending on one path only and answers with a vmcnt(0) mid-phase)
-        const int next_row = idxp[(size_t)min(s + 1, A.n_steps - 1) * FT_B + (tid >> 3)];
+        const int next_row = min(max(idxp[(size_t)min(s + 1, A.n_steps - 1) * FT_B + (tid >> 3)], 0), last_row);
         lds_barrier(); STAMP(1);
 
         // ---- F1: h1g -> T0, h1v -> T1 (one pass over the shared input)

@@ -1,7 +1,6 @@
 // Parameter-arena and workspace layout shared by host launchers and kernels.
 #pragma once
 #include <stdint.h>
-#include <stdlib.h>
 #include "../../include/ivae_amd.h"
 
 #define IVAE_MAX_LAYERS 8
@@ -87,10 +86,21 @@ static inline int ivae_check_dims(const IvaeDims* d) {
     if (d->activation < IVAE_ACT_NONE || d->activation > IVAE_ACT_SIGMOID) return IVAE_E_BADACT;
     if (d->latent_dim > 64 || d->data_dim > 1024 || d->aux_dim > 4096 || d->hidden_dim > 1024)
         return IVAE_E_TOOLARGE;
+    {   // the kernels form byte offsets into one (rows, features) / (features, rows) tensor in 32-bit integers
+        int w = d->hidden_dim > d->data_dim + d->aux_dim ? d->hidden_dim : d->data_dim + d->aux_dim;
+        if (d->latent_dim > w) w = d->latent_dim;
+        if (((int64_t)d->batch + 64) * (w + 4) * 4 >= ((int64_t)1 << 31)) return IVAE_E_TOOLARGE;
+    }
+    const int tr = d->tile_rows, nw = d->waves, wr = d->wgrad_rows;      // tuning fields: 0 = the library picks
+    if (tr != 0 && tr != 16 && tr != 32 && tr != 64) return IVAE_E_BADDIMS;
+    if (nw != 0 && nw != 4 && nw != 8 && nw != 16) return IVAE_E_BADDIMS;
+    if (wr != 0 && wr != 16 && wr != 32 && wr != 64 && wr != 128 && wr != 256) return IVAE_E_BADDIMS;
     return IVAE_OK;
 }
 
-static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
+// with_pair: the workspace also holds the pairwise kernels' scratch for a (B, B, dl) problem (ivae_elbo_fwd_bwd with
+// coef.pairwise); without it every part of the workspace is linear in the batch.
+static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo) {
     int rc = ivae_check_dims(d);
     if (rc) return rc;
     Layout& L = *Lo;
@@ -133,10 +143,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     // chunk round trips behind; the knob below still selects them), subject to the LDS fit further down
     int tr = 32;
     while (tr > 16 && (int64_t)((L.B + tr - 1) / tr) * L.n_models < 512) tr >>= 1;
-    if (const char* e = getenv("IVAE_AMD_TILE_ROWS")) {          // tuning knob: 16, 32 or 64
-        const int v = atoi(e);
-        if (v == 16 || v == 32 || v == 64) tr = v;
-    }
+    if (d->tile_rows) tr = d->tile_rows;                           // caller's choice (validated by ivae_check_dims)
     // waves per workgroup: 4 when the launch fills the chip by itself (several workgroups share a CU and hide each
     // other's latencies) or no product streams more than 64 output columns; otherwise a wider workgroup takes
     // 128 / 256 columns per chunk, so that a short dependent chain of layers needs fewer chunk round trips
@@ -145,10 +152,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     if (L.dl + 1 > jmax) jmax = L.dl + 1;
     int nw = 4;
     if ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 64) nw = jmax > 128 ? 16 : 8;
-    if (const char* e = getenv("IVAE_AMD_WAVES")) {              // tuning knob: 4, 8 or 16
-        const int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16) nw = v;
-    }
+    if (d->waves) nw = d->waves;
     ivae_tile_geometry(L, tr, nw);
     while (ivae_lds_over(L) && (nw > 4 || tr > 16)) {
         if (nw > 4) nw >>= 1; else tr >>= 1;
@@ -165,10 +169,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
         if (trw == 192) trw = 128;
         auto smem = [&](int t) { return 4 * (2 * IVAE_CHUNK_FLOATS(L.nw) + L.nT * (t + 4) + 64); };
         while (trw > 16 && ((int64_t)((L.B + trw - 1) / trw) * prods < 512 || smem(trw) > 64 * 1024)) trw >>= 1;
-        if (const char* e = getenv("IVAE_AMD_WGRAD_ROWS")) {       // tuning knob: 16, 32, 64, 128 or 256
-            const int v = atoi(e);
-            if (v == 16 || v == 32 || v == 64 || v == 128 || v == 256) trw = v;
-        }
+        if (d->wgrad_rows) trw = d->wgrad_rows;
         while (trw > 16 && smem(trw) > IVAE_LDS_LIMIT) trw >>= 1;
         if (smem(trw) > IVAE_LDS_LIMIT) return IVAE_E_TOOLARGE;
         L.trw = trw;
@@ -180,7 +181,7 @@ static inline int ivae_make_layout(const IvaeDims* d, Layout* Lo) {
     wso = (wso + 3) & ~(int64_t)3;
     L.ws_partial = take((int64_t)L.n_wtiles * L.slab_ld);
     L.ws_dz = take(Bl);
-    L.ws_pair = take((int64_t)ivae_pair_ws_floats(L.B, L.B, L.dl));
+    L.ws_pair = take(with_pair ? (int64_t)ivae_pair_ws_floats(L.B, L.B, L.dl) : 0);
     wso = (wso + 63) & ~(int64_t)63;
     L.ws.per_model = wso;
     return IVAE_OK;

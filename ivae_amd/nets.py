@@ -174,16 +174,26 @@ class _FusedModel(nn.Module):
             eps = torch.randn(x.shape[0], self._shape.latent_dim, dtype=torch.float32, device=x.device)
         return eps
 
+    FORWARD_ROWS = 65536     # rows per ivae_forward call: a full-dataset forward (runners/ivae.py:118-122) runs in blocks
+
     def _forward_tensors(self, x, u, eps=None):
         sh = self._shape
         eps = self._eps(x, eps)
         B = x.shape[0]
-        coef = ops.make_coef(decoder_var=self._decoder_var_f, global_batch=B)
-        z = ops.forward(sh, coef, self._flat_params(), x, u, eps, self._ws)
-        g = self._ws.view('g', B, sh.latent_dim).clone()
-        v = self._ws.view('v', B, sh.latent_dim).clone()
-        l = self._ws.view('l', B, sh.latent_dim).clone()
-        f = self._ws.view('f', B, sh.data_dim).clone()
+        params = self._flat_params()
+        mk = lambda w: torch.empty(B, w, dtype=torch.float32, device=x.device)
+        f, g, v, l, z = mk(sh.data_dim), mk(sh.latent_dim), mk(sh.latent_dim), mk(sh.latent_dim), mk(sh.latent_dim)
+        # every row's forward is independent of the others, so blocks give the same values as one call; the workspace
+        # (hidden activations of every layer) stays bounded for N = 1e6-row datasets
+        for lo in range(0, B, self.FORWARD_ROWS):
+            hi = min(B, lo + self.FORWARD_ROWS)
+            n = hi - lo
+            coef = ops.make_coef(decoder_var=self._decoder_var_f, global_batch=n)
+            z[lo:hi] = ops.forward(sh, coef, params, x[lo:hi], None if u is None else u[lo:hi], eps[lo:hi], self._ws)
+            g[lo:hi] = self._ws.view('g', n, sh.latent_dim)
+            v[lo:hi] = self._ws.view('v', n, sh.latent_dim)
+            l[lo:hi] = self._ws.view('l', n, sh.latent_dim)
+            f[lo:hi] = self._ws.view('f', n, sh.data_dim)
         return f, g, v, z, l
 
     def direct_step(self, optimizer, x, u, a, b, c, d, N, pairwise, eps=None, z_out=None):

@@ -10,6 +10,11 @@ from . import _lib
 from ._lib import ACT_IDS, IvaeCoef, IvaeDims, IvaeWsLayout, check
 
 
+# Tuning of the shape-generic kernels (IvaeDims.tile_rows / waves / wgrad_rows); 0 = the library picks.  Host-side default
+# for every IvaeDims this module forms; the library itself keeps no state.
+TUNING = {"tile_rows": 0, "waves": 0, "wgrad_rows": 0}
+
+
 @dataclass(frozen=True)
 class ModelShape:
     """Static shape of a model (constructor arguments of models/nets.py:125,190,392,550)."""
@@ -25,7 +30,8 @@ class ModelShape:
         if self.activation not in ACT_IDS:
             raise ValueError("Incorrect activation: {}".format(self.activation))
         return IvaeDims(batch, self.data_dim, self.latent_dim, self.aux_dim, self.hidden_dim, self.n_layers,
-                        ACT_IDS[self.activation], float(self.slope), n_models)
+                        ACT_IDS[self.activation], float(self.slope), n_models, int(TUNING["tile_rows"]),
+                        int(TUNING["waves"]), int(TUNING["wgrad_rows"]))
 
     @property
     def mlps(self):
@@ -65,15 +71,15 @@ def make_coef(a=1., b=1., c=1., d=1., N=1., decoder_var=.01, pairwise=False, glo
                     int(global_batch))
 
 
-def workspace_bytes(dims):
+def workspace_bytes(dims, pairwise=True):
     n = C.c_size_t()
-    check(_lib.lib().ivae_workspace_bytes(C.byref(dims), C.byref(n)), "ivae_workspace_bytes")
+    check(_lib.lib().ivae_workspace_bytes(C.byref(dims), int(bool(pairwise)), C.byref(n)), "ivae_workspace_bytes")
     return n.value
 
 
-def workspace_layout(dims):
+def workspace_layout(dims, pairwise=True):
     lay = IvaeWsLayout()
-    check(_lib.lib().ivae_workspace_layout(C.byref(dims), C.byref(lay)), "ivae_workspace_layout")
+    check(_lib.lib().ivae_workspace_layout(C.byref(dims), int(bool(pairwise)), C.byref(lay)), "ivae_workspace_layout")
     return lay
 
 
@@ -85,13 +91,15 @@ class Workspace:
         self.key = None
         self.layout = None
 
-    def get(self, dims, device):
-        key = tuple(getattr(dims, f) for f, _ in dims._fields_) + (str(device),)
+    def get(self, dims, device, pairwise):
+        """Scratch for calls with this (dims, coef.pairwise): the layout depends on both."""
+        pairwise = bool(pairwise)
+        key = tuple(getattr(dims, f) for f, _ in dims._fields_) + (str(device), pairwise)
         if key != self.key:
-            nbytes = workspace_bytes(dims)
+            nbytes = workspace_bytes(dims, pairwise)
             if self.buf is None or self.buf.numel() * 4 < nbytes or self.buf.device != device:
                 self.buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-            self.layout = workspace_layout(dims)
+            self.layout = workspace_layout(dims, pairwise)
             self.key = key
         return self.buf
 
@@ -117,7 +125,7 @@ def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, z_out=None):
     dims = shape.dims(B, n_models)
     dev = x.device
     with torch.cuda.device(dev):
-        buf = ws.get(dims, dev)
+        buf = ws.get(dims, dev, coef.pairwise)
         if z_out is None:
             z = torch.empty(x.shape[:-1] + (shape.latent_dim,), dtype=torch.float32, device=dev)
         else:
@@ -151,7 +159,7 @@ def elbo_adam_steps(shape, coef, params, exp_avg, exp_avg_sq, x_steps, u_steps, 
     dims = shape.dims(B, n_models)
     dev = x_steps.device
     with torch.cuda.device(dev):
-        buf = ws.get(dims, dev)
+        buf = ws.get(dims, dev, coef.pairwise)
         if z_out is None:
             z = torch.empty_like(eps_steps)
         else:
@@ -177,7 +185,7 @@ def forward(shape, coef, params, x, u, eps, ws, n_models=1):
     dims = shape.dims(B, n_models)
     dev = x.device
     with torch.cuda.device(dev):
-        buf = ws.get(dims, dev)
+        buf = ws.get(dims, dev, coef.pairwise)
         z = torch.empty(x.shape[:-1] + (shape.latent_dim,), dtype=torch.float32, device=dev)
         check(_lib.lib().ivae_forward(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps), _ptr(z),
                                       _ptr(buf), buf.numel() * 4, _stream(dev)), "ivae_forward")
@@ -213,7 +221,7 @@ def backward(shape, coef, params, x, u, eps, ws, n_models=1):
     dims = shape.dims(B, n_models)
     dev = x.device
     with torch.cuda.device(dev):
-        buf = ws.get(dims, dev)
+        buf = ws.get(dims, dev, coef.pairwise)
         loss = torch.empty(n_models, dtype=torch.float32, device=dev)
         grads = torch.empty_like(params)
         check(_lib.lib().ivae_backward(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps),

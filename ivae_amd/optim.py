@@ -13,7 +13,11 @@ from . import ops
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # every key torch.optim.Adam keeps in a param group, at the only values this optimiser implements, so that a
+        # state_dict saved here loads into torch.optim.Adam (its load_state_dict takes the SAVED groups) and back
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self._flat = None        # (params tuple, flat_m, flat_v) of the direct path (step_flat)
         self._flat_key = None    # the param list those were built for
         self._pending = 0        # steps taken by step_flat not yet written to the per-parameter `step` entries
@@ -76,6 +80,41 @@ class FusedAdam(torch.optim.Optimizer):
     def state_dict(self):
         self._sync_steps_keep()
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam's state_dict (what utils/utils.py:55-64 stores under 'optimizer_state_dict') or our own:
+        the loaded exp_avg / exp_avg_sq are re-packed into ONE flat buffer per group (a checkpoint loaded with
+        map_location='cpu' arrives as separate tensors) and every cache of the direct path is dropped, so step(),
+        step_flat() and flat_state() continue from the loaded moments and step count."""
+        self._pending = 0                     # steps of the state being replaced
+        super().load_state_dict(state_dict)
+        self._reset_flat()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault('_pending', 0)
+        self._reset_flat()
+
+    def _reset_flat(self):
+        self._flat, self._flat_key, self._pending = None, None, 0
+        for group in self.param_groups:
+            if group.get('weight_decay', 0) != 0 or group.get('amsgrad', False) or group.get('maximize', False):
+                raise NotImplementedError('FusedAdam implements torch.optim.Adam with weight_decay=0, amsgrad=False, '
+                                          'maximize=False (what the reference uses: runners/ivae.py:38, wrappers.py:44)')
+            ps = [p for p in group['params'] if len(self.state.get(p, {}))]
+            if not ps:
+                continue
+            total = sum(p.numel() for p in ps)
+            m = torch.empty(total, dtype=torch.float32, device=ps[0].device)
+            v = torch.empty_like(m)
+            off = 0
+            for p in ps:
+                n, st = p.numel(), self.state[p]
+                m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                st['exp_avg'], st['exp_avg_sq'] = m[off:off + n].view(p.shape), v[off:off + n].view(p.shape)
+                st['step'] = torch.tensor(float(st['step']))          # host scalar, as torch.optim.Adam keeps it
+                off += n
 
     def _sync_steps_keep(self):
         if self._pending:

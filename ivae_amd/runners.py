@@ -58,9 +58,15 @@ def _assignment_scores(cc_abs):
 
 
 # ------------------------------------------------------------------------------------------------ family A
-def runner(args, config):
+def runner(args, config, *, replay=None, trace=None):
     """runners/ivae.py:13-128.  `args`: data_path, seed, n_sims.  `config`: the yaml keys of configs/*.yaml plus
-    `device`.  Returns (perfs, loss_hists, perf_hists)."""
+    `device`.  Returns (perfs, loss_hists, perf_hists).
+
+    Test hooks (tests/test_gpu_runner_trace.py replays runs recorded from the reference's runner draw for draw):
+    `replay` supplies the random draws instead of the device generators -- `replay.order(seed, epoch)` the epoch's row
+    order (N // B * B indices), `replay.eps(seed, epoch)` the (N // B, B, d_latent) noise of its steps,
+    `replay.eval_eps(seed)` the (N, d_latent) noise of the final full-data sample; `trace` (a dict) receives the
+    per-step losses, and per epoch the loss weights and the learning rate after the scheduler's step."""
     st = time.time()
     device = torch.device(config.device)
     print('Executing script on: {}\n'.format(device))
@@ -96,11 +102,15 @@ def runner(args, config):
                     a, b, c, d = 2 * config.a, 1, 1, 1
             # one gather per epoch (DataLoader(shuffle=True, drop_last=True), runners/ivae.py:25); batches are views
             nb = N // B
-            perm = torch.randperm(N, device=device, generator=gen)[:nb * B]
+            if replay is None:
+                perm, eps = torch.randperm(N, device=device, generator=gen)[:nb * B], None
+            else:
+                perm, eps = replay.order(seed, epoch).to(device), replay.eps(seed, epoch).to(device)
             Xe, Ue, Se = X[perm].view(nb, B, -1), U[perm].view(nb, B, -1), S[perm].view(nb, B, -1)
             Ze = torch.empty(nb, B, d_latent, device=device)
             # zero_grad -> elbo -> backward -> step (runners/ivae.py:75-91) of the whole epoch enqueued by one call
-            losses, _ = model.direct_steps(optimizer, Xe, Ue if config.ica else None, a, b, c, d, N, True, z_out=Ze)
+            losses, _ = model.direct_steps(optimizer, Xe, Ue if config.ica else None, a, b, c, d, N, True, eps=eps,
+                                           z_out=Ze)
             cc = ops.corr_batched(Se, Ze)       # the per-step batch scores (runners/ivae.py:86), one launch per epoch
             train_loss = float(losses.sum().item()) / nb      # the epoch's one sync
             train_perf = float(np.mean(_assignment_scores(cc.abs().cpu().numpy())))
@@ -110,11 +120,16 @@ def runner(args, config):
                                                                                     train_perf))
             if not config.no_scheduler:
                 scheduler.step(train_loss)
+            if trace is not None:
+                trace.setdefault('step_loss', []).append(losses.cpu())
+                trace.setdefault('coef', []).append((a, b, c, d))
+                trace.setdefault('lr', []).append(optimizer.param_groups[0]['lr'])
         print('\ntotal runtime: {}'.format(time.time() - st))
 
         # full-dataset score on a SAMPLE of q(z|x,u), as the reference does (runners/ivae.py:118-123)
         with torch.no_grad():
-            s = model(X, U)[3] if config.ica else model(X)[3]
+            ev = None if replay is None else replay.eval_eps(seed).to(device)
+            s = model(X, U, eps=ev)[3] if config.ica else model(X, eps=ev)[3]
         perfs.append(mcc(S, s))
         loss_hists.append(loss_hist)
         perf_hists.append(perf_hist)

@@ -57,6 +57,26 @@ class Spec:
                 out += [f"{m}.fc.{li}.weight", f"{m}.fc.{li}.bias"]
         return out
 
+    def param_shapes(self):
+        """Shapes in param_names() order: weight (out, in) then bias (out,) per layer."""
+        out = []
+        for m in self.mlps:
+            for i, o in self.layer_dims(m):
+                out += [(o, i), (o,)]
+        return out
+
+    def unflatten(self, flat):
+        """One model's flat arena (parameters() order) -> {name: array}."""
+        P, off = {}, 0
+        for n, shp in zip(self.param_names(), self.param_shapes()):
+            k = 1
+            for v in shp:
+                k *= v
+            P[n] = flat[off:off + k].reshape(shp)
+            off += k
+        assert off == flat.size
+        return P
+
     def n_params(self):
         return sum((i + 1) * o for m in self.mlps for i, o in self.layer_dims(m))
 

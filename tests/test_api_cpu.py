@@ -45,7 +45,7 @@ def test_bad_shapes_return_error_codes():
     assert L.ivae_param_count(C.byref(_lib.IvaeDims(64, 10, 100, 40, 50, 3, 1, .1, 1)), C.byref(n)) == -4
     assert L.ivae_param_count(C.byref(_lib.IvaeDims(64, 10, 10, 40, 50, 3, 1, .1, 1)), None) == -3
     nb = C.c_size_t()
-    assert L.ivae_workspace_bytes(C.byref(_lib.IvaeDims(64, 10, 10, 40, 50, 3, 1, .1, 1)), C.byref(nb)) == 0
+    assert L.ivae_workspace_bytes(C.byref(_lib.IvaeDims(64, 10, 10, 40, 50, 3, 1, .1, 1)), 1, C.byref(nb)) == 0
     assert nb.value > 64 * 400 * 4
     assert L.ivae_corr_workspace_bytes(1, 5, C.byref(nb)) == -1
     assert L.ivae_adam_step(None, None, None, None, 10, .01, .9, .999, 1e-8, 1, None) == -3
@@ -58,14 +58,34 @@ def test_bad_shapes_return_error_codes():
     assert L.ivae_elbo_adam_steps(*args(good, 0, 0)) == -1
     assert L.ivae_elbo_adam_steps(*args(good, 3, -1)) == -1
     assert L.ivae_elbo_adam_steps(*args(_lib.IvaeDims(64, 10, 10, 40, 50, 3, 9, .1, 1), 3, 0)) == -2
-    # every row tiling / wave count the knobs can pin yields a layout (and a workspace size) for the yaml shapes
-    for rows, waves, wrows in ((16, 4, 16), (64, 16, 256), (32, 8, 64)):
-        os.environ.update(IVAE_AMD_TILE_ROWS=str(rows), IVAE_AMD_WAVES=str(waves), IVAE_AMD_WGRAD_ROWS=str(wrows))
-        try:
-            assert L.ivae_workspace_bytes(C.byref(_lib.IvaeDims(1024, 5, 5, 0, 100, 3, 2, .1, 1)), C.byref(nb)) == 0 and nb.value > 0
-        finally:
-            for k in ("IVAE_AMD_TILE_ROWS", "IVAE_AMD_WAVES", "IVAE_AMD_WGRAD_ROWS"):
-                os.environ.pop(k, None)
+    # every row tiling / wave count the tuning fields can pin yields a layout (and a workspace size) for the yaml shapes
+    for rows, waves, wrows in ((16, 4, 16), (64, 16, 256), (32, 8, 64), (0, 0, 0)):
+        dims = _lib.IvaeDims(1024, 5, 5, 0, 100, 3, 2, .1, 1, rows, waves, wrows)
+        assert L.ivae_workspace_bytes(C.byref(dims), 1, C.byref(nb)) == 0 and nb.value > 0
+    for bad in ((17, 0, 0), (0, 5, 0), (0, 0, 100), (-16, 0, 0)):
+        assert L.ivae_workspace_bytes(C.byref(_lib.IvaeDims(1024, 5, 5, 0, 100, 3, 2, .1, 1, *bad)), 1, C.byref(nb)) == -1
+    # a batch whose 32-bit byte offsets would overflow is refused, not mis-addressed
+    assert L.ivae_workspace_bytes(C.byref(_lib.IvaeDims(600000, 10, 10, 40, 1024, 3, 1, .1, 1)), 0, C.byref(nb)) == -4
+
+
+def test_plain_workspace_is_linear_in_the_batch():
+    """Without the pairwise term nothing in the workspace is quadratic in the batch: a full-dataset forward
+    (runners/ivae.py:118-122, N = 40000 ... 1e6 rows in one call) must not pay for the pairwise kernels' scratch."""
+    L = _lib.lib()
+    size = lambda B, pw: (lambda n: (L.ivae_workspace_bytes(C.byref(_lib.IvaeDims(B, 10, 10, 40, 50, 3, 1, .1, 1)), pw,
+                                                            C.byref(n)), n.value))(C.c_size_t())
+    (rc1, a), (rc2, b), (rc3, c) = size(4096, 0), size(40960, 0), size(409600, 0)
+    assert rc1 == rc2 == rc3 == 0
+    assert abs(b / a - 10) < 0.2 and abs(c / a - 100) < 2, (a, b, c)
+    rc, q = size(40960, 1)
+    assert rc == 0 and q > b + 100e6            # the pairwise scratch is what grows quadratically
+    lay0, lay1 = _lib.IvaeWsLayout(), _lib.IvaeWsLayout()
+    d = _lib.IvaeDims(4096, 10, 10, 40, 50, 3, 1, .1, 1)
+    assert L.ivae_workspace_layout(C.byref(d), 0, C.byref(lay0)) == 0 and L.ivae_workspace_layout(C.byref(d), 1, C.byref(lay1)) == 0
+    for f, _ in _lib.IvaeWsLayout._fields_:     # row-tensor offsets do not depend on the flag, only the model stride does
+        if f != "per_model":
+            assert getattr(lay0, f) == getattr(lay1, f), f
+    assert lay1.per_model > lay0.per_model
 
 
 def _build(c):

@@ -268,6 +268,17 @@ def test_corr_kernel_matches_numpy_corrcoef(golden_dir):
         ivae_amd.mean_corr_coef(z["x0"], torch.from_numpy(z["y0"]))
 
 
+def test_corr_at_the_widest_supported_d():
+    """d = 64: k_corr_moments needs 66 KB of dynamic LDS, above the default 64 KB limit (per-device attribute)."""
+    rng = np.random.RandomState(3)
+    x = rng.randn(700, 64).astype(np.float32)
+    y = (x @ rng.randn(64, 64).astype(np.float32) * 0.1 + rng.randn(700, 64)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    ref = np.corrcoef(x.astype(np.float64), y.astype(np.float64), rowvar=False)[:64, 64:]
+    assert np.abs(ops.corr(t(x), t(y)).cpu().numpy() - ref).max() < 1e-12
+    assert np.abs(ops.corr_batched(t(x)[None], t(y)[None]).cpu().numpy()[0] - ref).max() < 1e-12
+
+
 def test_corr_large_n_property():
     """Full-size property check (N = 40000 x d = 10, the final-eval shape of runners/ivae.py:123):
     corr(x, x) has unit diagonal, corr is invariant to affine maps, symmetric under swap."""
@@ -302,10 +313,10 @@ def test_bad_inputs_raise():
                                   "ivae_plain_l4_none", "ivae_plain_l1"])
 def test_every_row_tiling_matches_reference_fixture(name, tile_rows, waves, monkeypatch):
     """The generic kernels pick 16, 32 or 64 batch rows and 4, 8 or 16 waves per workgroup from the launch geometry
-    (each pair is its own wave -> tile map and chunk width); IVAE_AMD_TILE_ROWS / IVAE_AMD_WAVES pin the choice so that
+    (each pair is its own wave -> tile map and chunk width); IvaeDims.tile_rows / .waves pin the choice so that
     every variant meets the same 1e-5 bar on ragged batches, H = 100 xtanh, 1- and 4-layer MLPs."""
-    monkeypatch.setenv("IVAE_AMD_TILE_ROWS", str(tile_rows))
-    monkeypatch.setenv("IVAE_AMD_WAVES", str(waves))
+    monkeypatch.setitem(ops.TUNING, "tile_rows", tile_rows)
+    monkeypatch.setitem(ops.TUNING, "waves", waves)
     c = Case(name)
     loss, z, grads, ws = run_case(c)
     assert abs(float(loss[0]) - c.loss()) <= TOL * abs(c.loss())
@@ -378,9 +389,9 @@ def test_corr_batched_matches_numpy_corrcoef(nb, n, d):
 @pytest.mark.parametrize("name", ["ivae_plain_b70", "cleanvae_btcvae_b200", "ivae_plain_cfg4s"])
 def test_every_wgrad_row_tiling_matches_reference_fixture(name, wgrad_rows, monkeypatch):
     """k_wgrad tiles the batch on its own (its rows are the contraction length of a weight gradient);
-    IVAE_AMD_WGRAD_ROWS pins the tile so that every contraction length (one to four k chunks, ragged last tiles, tiles
+    IvaeDims.wgrad_rows pins the tile so that every contraction length (one to four k chunks, ragged last tiles, tiles
     longer than the batch) meets the same 1e-5 bar."""
-    monkeypatch.setenv("IVAE_AMD_WGRAD_ROWS", str(wgrad_rows))
+    monkeypatch.setitem(ops.TUNING, "wgrad_rows", wgrad_rows)
     c = Case(name)
     loss, z, grads, ws = run_case(c)
     assert abs(float(loss[0]) - c.loss()) <= TOL * abs(c.loss())

@@ -30,3 +30,47 @@ def test_two_rank_split_covers_the_grid_once():
         lo, hi = model_range(len(runs), r, 8)
         got += runs[lo:hi]
     assert got == runs
+
+
+@pytest.mark.parametrize("d", [20, 40])
+def test_sweep_dims_20_and_40_as_32_model_packs_match_fp64_oracle(d):
+    """BASELINE configs[4] at its upper dims: the (d, d, 40, 50) plain-ELBO shape as a pack of 32 independently
+    initialised models, batch 64, one ivae_elbo_fwd_bwd + ivae_adam_step over the whole pack -- loss, z and EVERY
+    gradient tensor of EVERY model against the fp64 oracle (no reference fixture at these shapes: the oracle is pinned
+    by the fixtures at others), first-step Adam moments = 0.1 * grad."""
+    from ivae_amd import ops
+    from ivae_amd.trainer import init_packed_params
+    from oracle import np_ref
+    from tests.util import relmax
+    dev = torch.device("cuda:0")
+    nm, B = 32, 64
+    shape = ops.ModelShape(d, d, 40, 50, 3, "lrelu", .1)
+    spec = np_ref.Spec(d, d, 40)
+    names = spec.param_names()
+    rng = np.random.RandomState(d)
+    x = (rng.randn(nm, B, d) * 1.5).astype(np.float32)
+    u = np.zeros((nm, B, 40), np.float32)
+    lab = rng.randint(0, 40, (nm, B))
+    for m in range(nm):
+        u[m, np.arange(B), lab[m]] = 1
+    eps = rng.randn(nm, B, d).astype(np.float32)
+    P = init_packed_params(shape, nm, seed=d, device=dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    coef = ops.make_coef(decoder_var=.01, global_batch=B)
+    loss, z, grads = ops.elbo_fwd_bwd(shape, coef, P, t(x), t(u), t(eps), ops.Workspace(), n_models=nm)
+    m1, v1, p1 = torch.zeros_like(P), torch.zeros_like(P), P.clone()
+    ops.adam_step(p1.view(-1), m1.view(-1), v1.view(-1), grads.view(-1), 1e-2, 1)
+    Ph, G, Z, M1 = P.cpu().numpy(), grads.cpu().numpy(), z.cpu().numpy(), m1.cpu().numpy()
+    ocoef = np_ref.Coef(pairwise=False)
+    for m in range(nm):
+        Pm = spec.unflatten(Ph[m])
+        fw = np_ref.elbo_forward(Pm, x[m], u[m], eps[m], spec, ocoef, np.float64)
+        Gm = np_ref.elbo_backward(Pm, x[m], u[m], fw, spec, ocoef, np.float64)
+        assert abs(float(loss[m]) - float(fw["loss"])) <= 1e-5 * abs(float(fw["loss"])), m
+        assert relmax(Z[m], fw["z"]) < 1e-5, m
+        off = 0
+        for n in names:
+            k = Gm[n].size
+            assert relmax(G[m, off:off + k], Gm[n].reshape(-1)) < 1e-5, (m, n)
+            assert relmax(M1[m, off:off + k], 0.1 * Gm[n].reshape(-1)) < 1e-5, (m, n)
+            off += k

@@ -25,14 +25,14 @@ loss, z, grads = ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws)
 print("adam host/total us:", t(lambda: ops.adam_step(params, m, v, grads, 1e-3, 1)))
 print("torch.empty x3:", t(lambda: (torch.empty(B, 10, device=dev), torch.empty(1, device=dev), torch.empty_like(params))))
 dims = shape.dims(B, 1)
-buf = ws.get(dims, dev)
+buf = ws.get(dims, dev, False)
 L = _lib.lib()
 zz = torch.empty(B, 10, device=dev); ll = torch.empty(1, device=dev); gg = torch.empty_like(params)
 st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 def raw():
     L.ivae_elbo_fwd_bwd(C.byref(dims), C.byref(coef), C.c_void_p(params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(eps.data_ptr()), C.c_void_p(zz.data_ptr()), C.c_void_p(ll.data_ptr()), C.c_void_p(gg.data_ptr()), C.c_void_p(buf.data_ptr()), buf.numel() * 4, st)
 print("raw ctypes ivae_elbo_fwd_bwd:", t(raw))
-print("ws.get:", t(lambda: ws.get(dims, dev)))
+print("ws.get:", t(lambda: ws.get(dims, dev, False)))
 def ctx():
     with torch.cuda.device(dev): pass
 print("cuda.device ctx:", t(ctx))

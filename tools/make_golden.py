@@ -246,8 +246,137 @@ def make_traces(n_seeds=4, epochs=2, B=64):
     np.savez_compressed(os.path.join(OUT, "trace_cfg2.npz"), **out)
 
 
+# ---- family-A loop traces: the reference's own runners/ivae.py::runner, run unmodified ------------------------------
+RUNNER_CASES = [
+    # name, yaml file of the reference, config overrides, seeds, epochs
+    ("ivae", "ivae.yaml", {}, (0, 1), 2),
+    ("btcvae", "btcvae.yaml", {}, (0, 1), 2),
+    ("ivae_anneal", "ivae.yaml", {"anneal": True}, (0,), 3),     # epoch > epochs/1.6 switches the weights at epoch 2
+]
+
+
+def noise_seed(seed, step):
+    """Seed of the torch.randn(B, d) draw of training step `step` (the trace fixes it so the draw can be replayed)."""
+    return 1_000_000 * (seed + 1) + step
+
+
+def eval_seed(seed):
+    return 777 + seed
+
+
+def make_runner_traces():
+    """Run `runners.ivae.runner(args, config)` of the reference (runners/ivae.py:13-128) exactly as main.py:47-62 does --
+    np.random.seed / torch.manual_seed(seed), yaml -> Namespace -- on CPU, with recording shims only:
+      * the dataset's __getitem__ logs the row order the DataLoader(shuffle=True, drop_last=True) asked for;
+      * the model's elbo() seeds the global generator per step (noise_seed) so that its randn draw can be replayed, and
+        logs the loss and the (a, b, c, d) it was called with; the full-dataset forward of :118-122 is seeded by eval_seed;
+      * ReduceLROnPlateau drops the `verbose` argument current torch rejects and logs the learning rate after step();
+      * np.int alias for numpy 2 (data/data.py:32).
+    -> tests/golden/trace_runner.npz: per run the batch order, per-step losses, per-epoch loss / perf / lr / weights and
+    the final full-data MCC, replayed through ivae_amd.runners.runner by tests/test_gpu_runner_trace.py."""
+    import argparse
+    import tempfile
+    import yaml
+    if not hasattr(np, "int"):
+        np.int = int
+    import runners.ivae as R
+
+    rec = argparse.Namespace()
+
+    class RecDataset(R.SyntheticDataset):
+        def __getitem__(self, index):
+            rec.order.append(int(index))
+            return super().__getitem__(index)
+
+    def recording(base):
+        class Rec(base):
+            def __init__(self, *a, **kw):
+                super().__init__(*a, **kw)
+                if rec.perturb:      # sensitivity runs: initial parameters moved by ~1e-6 relative (a few fp32 roundings)
+                    gen = torch.Generator().manual_seed(4242 + rec.perturb)
+                    with torch.no_grad():
+                        for p in self.parameters():
+                            p.mul_(1 + 1e-6 * torch.randn(p.shape, generator=gen))
+
+            def elbo(self, x, u, N, a=1., b=1., c=1., d=1.):
+                torch.manual_seed(noise_seed(rec.seed, rec.step))
+                loss, z = super().elbo(x, u, N, a=a, b=b, c=c, d=d)
+                rec.losses.append(float(loss.item()))
+                rec.coefs.append((a, b, c, d))
+                rec.step += 1
+                return loss, z
+
+            def forward(self, x, *rest):
+                if x.shape[0] == rec.N:
+                    torch.manual_seed(eval_seed(rec.seed))
+                return super().forward(x, *rest)
+        return Rec
+
+    class RecPlateau(torch.optim.lr_scheduler.ReduceLROnPlateau):
+        def __init__(self, optimizer, *a, verbose=None, **kw):
+            super().__init__(optimizer, *a, **kw)
+
+        def step(self, metrics, *a, **kw):
+            super().step(metrics, *a, **kw)
+            rec.lrs.append(self.optimizer.param_groups[0]["lr"])
+
+    saved = (R.SyntheticDataset, R.cleanIVAE, R.cleanVAE, torch.optim.lr_scheduler.ReduceLROnPlateau)
+    R.SyntheticDataset, R.cleanIVAE, R.cleanVAE = RecDataset, recording(R.cleanIVAE), recording(R.cleanVAE)
+    torch.optim.lr_scheduler.ReduceLROnPlateau = RecPlateau
+    out, index = {}, []
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            for name, yml, over, seeds, epochs in RUNNER_CASES:
+                with open(os.path.join(REF, "configs", yml)) as f:
+                    cfg = yaml.safe_load(f)
+                cfg.update(over)
+                cfg["epochs"] = epochs
+                for seed in seeds:
+                    config = argparse.Namespace(**cfg)
+                    config.device = torch.device("cpu")
+                    args = argparse.Namespace(data_path=tmp + "/", seed=seed, n_sims=1)
+
+                    def run(perturb):
+                        rec.seed, rec.step, rec.N, rec.perturb = seed, 0, cfg["nps"] * cfg["ns"], perturb
+                        rec.order, rec.losses, rec.coefs, rec.lrs = [], [], [], []
+                        np.random.seed(seed)
+                        torch.manual_seed(seed)
+                        return R.runner(args, config)
+
+                    key = f"{name}.s{seed}"
+                    if seed == seeds[0]:
+                        # How far does the REFERENCE move when its initial parameters move by 1e-6 relative (same batch
+                        # order: the shuffle is seeded by the per-step noise seeds; same noise)?  Hundreds of Adam steps
+                        # amplify round-off; the replay test holds ivae_amd to a multiple of this measured spread.
+                        sens = [run(k) for k in (1, 2)]
+                        out[key + ".sens_loss_hist"] = np.array([r_[1][0] for r_ in sens], np.float64)
+                        out[key + ".sens_perf_hist"] = np.array([r_[2][0] for r_ in sens], np.float64)
+                        out[key + ".sens_perf"] = np.array([r_[0][0] for r_ in sens], np.float64)
+                    perfs, loss_hists, perf_hists = run(0)
+                    if seed == seeds[0]:
+                        print(f"  sensitivity {key}: perf_hist {out[key + '.sens_perf_hist'].tolist()} perf {out[key + '.sens_perf'].tolist()}")
+                    B = cfg["batch_size"]
+                    nb = rec.N // B
+                    assert len(rec.order) == epochs * nb * B and len(rec.losses) == epochs * nb
+                    out[key + ".order"] = np.array(rec.order, np.uint16 if rec.N <= 65536 else np.int32)
+                    out[key + ".step_loss"] = np.array(rec.losses, np.float32)
+                    out[key + ".step_coef"] = np.array(rec.coefs[::nb], np.float32)       # one row per epoch
+                    out[key + ".lr"] = np.array(rec.lrs, np.float64)
+                    out[key + ".loss_hist"] = np.array(loss_hists[0], np.float64)
+                    out[key + ".perf_hist"] = np.array(perf_hists[0], np.float64)
+                    out[key + ".perf"] = np.array(perfs[0], np.float64)
+                    index.append(dict(key=key, name=name, seed=seed, epochs=epochs, config=cfg))
+                    print(f"runner trace {key}: loss {loss_hists[0]} perf {perf_hists[0]} lr {rec.lrs} full perf {perfs[0]:.4f}")
+    finally:
+        R.SyntheticDataset, R.cleanIVAE, R.cleanVAE, torch.optim.lr_scheduler.ReduceLROnPlateau = saved
+    out["index"] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, "trace_runner.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "runner_traces":
+        return make_runner_traces()
     if len(sys.argv) > 1 and sys.argv[1] == "datasets":
         return make_datasets()
     if len(sys.argv) > 1 and sys.argv[1] == "traces":
