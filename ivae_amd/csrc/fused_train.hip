@@ -99,7 +99,7 @@ struct FCfg {
     static constexpr int NADAM = reg_of(N_LAYERS);
     static constexpr int TILE = FT_B * ST, SMALL = FT_B * SS;
     static constexpr int STG_F2 = H * KS_H;                         // offset of the decoder-head gradient stage inside its tile
-    static constexpr int LDS_FLOATS = ARENA + 5 * TILE + 4 * SMALL + 64;   // +64: slack for tile over-reads past the last row
+    static constexpr int LDS_FLOATS = ARENA + 5 * TILE + 5 * SMALL;         // d = 10: exactly the 160 KB
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
     static constexpr int NXD = cdiv(DD_, 8), NXM = cdiv(M_, 8);     // prefetch registers: thread = (row, every 8th column)
     static constexpr int NXU = NXD + NXM;
@@ -160,6 +160,9 @@ __device__ __forceinline__ float lrelu(float p, float slope) { return fmaxf(p, p
 
 // natural log on the hardware log2 unit (v_log_f32, 1 ulp in log2)
 __device__ __forceinline__ float flog(float x) { return 0.6931471805599453f * __builtin_amdgcn_logf(x); }
+
+// e^x on the hardware exp2 unit (v_exp_f32, 1 ulp in exp2; the argument's rounding adds |x| * 6e-8 relative)
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
 
 #define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
 // LDS offsets are far below 2^23: full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
@@ -379,14 +382,17 @@ __device__ __forceinline__ f32x4 mm_wgrad1(const float* ycol, int sy, const floa
 template <class C>
 __device__ __forceinline__ void fwd_epilogue_row(f32x4 (&keep)[2], int r, float* out, float slope, int w, int lane) {
     const int c = lane & 15, q = lane >> 4;
-    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    // lanes whose column pair lies past the tile's last one act on that last pair (H, H + 1: the constant-1 and zero
+    // columns) and write the same values there as its owner: no exec-masked store, no branch
+    const int rt = w & 3, col0 = min(32 * (w >> 2) + 2 * c, C::ST - 2);
+    static_assert(C::ST - 2 >= C::H, "the clamped column pair holds no product column");
     const bool in0 = col0 < C::H, in1 = col0 + 1 < C::H;
     const float f0 = col0 == C::H ? 1.f : 0.f, f1 = col0 + 1 == C::H ? 1.f : 0.f;
     const float v0 = in0 ? lrelu(keep[0][r], slope) : f0;
     const float v1 = in1 ? lrelu(keep[1][r], slope) : f1;
     keep[0][r] = v0;
     keep[1][r] = v1;
-    if (col0 < C::ST) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
+    st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
 }
 
 // Product of hidden layer(s) for NW weight matrices that share the input tile: acc_w = X W_w^T (no epilogue).
@@ -419,15 +425,76 @@ __device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* 
         for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(keep[m], r, out[m], slope, w, lane);
 }
 
+// ---- wave-local forward chains.  In the forward stage a wave owns a whole 16-row tile of ONE chain (all 64 output
+// columns = two interleaved tile pairs), so layer l+1 of the chain reads only rows the same wave wrote: no workgroup
+// barrier between the layers of a chain.  keep[p][j] is the pair p = columns 32p + 2c + j.
+template <class C, int KS, class F>
+__device__ __forceinline__ void fwd_rows_product(const float* X, int sx, const float* W, int rt, int lane,
+                                                 f32x4 (&keep)[2][2], F&& fill) {
+    const int c = lane & 15, q = lane >> 4;
+    const float* wrow[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int col0 = 32 * p + 2 * c;
+        wrow[p][0] = W + mul24(min(col0, C::H - 1), KS);
+        wrow[p][1] = W + mul24(min(col0 + 1, C::H - 1), KS);
+        keep[p][0] = ZERO4;
+        keep[p][1] = ZERO4;
+    }
+    mm_fwd<2, KS>(X + mul24(16 * rt + c, sx), wrow, q, keep, fill);
+}
+
+// out[b][n] = lrelu(X[b][:] . W[n][:]) for the 16 rows of tile rt, every column; values kept for the stash.
+template <class C, int KS>
+__device__ __forceinline__ void fwd_rows(const float* X, int sx, const float* W, float* out, float slope, int rt,
+                                         f32x4 (&keep)[2][2]) {
+    const int lane = opaque_lane();
+    fwd_rows_product<C, KS>(X, sx, W, rt, lane, keep, NoFill());
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(keep[p], r, out, slope, rt + 4 * p, lane);
+}
+
+// Hand-offs between the two waves that own one row tile (waves rt and rt + 4: the two waves of one SIMD) inside the
+// forward stage.  A flag is one LDS word holding the number of the step it was last raised in; it lives in the unused
+// pad column of the resident input tile (column KIN + 1 of T3, which multiplies zero weight columns only).  The
+// producer drains its LDS traffic before raising it; LDS operations of a CU complete in issue order, so a consumer that
+// sees the flag sees the data.  The wait is bounded: a protocol error ends in wrong numbers, never in a hung GPU.
+// (Explicit LDS address space: through a generic pointer these would be FLAT accesses, whose wait also drains the
+// global loads of the next batch's prefetch.)
+typedef __attribute__((address_space(3))) volatile int lds_flag_t;
+#ifndef FT_POLL_SLEEP
+#define FT_POLL_SLEEP 1
+#endif
+__device__ __forceinline__ void flag_raise(float* flag, int step_no) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *(lds_flag_t*)flag = step_no;
+}
+__device__ __forceinline__ void flag_wait(const float* flag, int step_no) {
+#pragma unroll 1
+    for (int spin = 0; spin < (1 << 18); ++spin) {
+        if (*(lds_flag_t*)flag >= step_no) break;
+        __builtin_amdgcn_s_sleep(FT_POLL_SLEEP);
+    }
+    asm volatile("" ::: "memory");
+}
+
 // Write a stashed hidden activation (post-epilogue values kept in registers) back to an LDS tile.
 template <class C>
 __device__ __forceinline__ void restore_tile(const f32x4 (&keep)[2], float* out, int w) {
     const int lane = opaque_lane();
     const int c = lane & 15, q = lane >> 4;
-    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    const int rt = w & 3, col0 = min(32 * (w >> 2) + 2 * c, C::ST - 2);      // clamped like the epilogue that filled `keep`
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (col0 < C::ST) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, keep[0][r], keep[1][r]);
+    for (int r = 0; r < 4; ++r) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, keep[0][r], keep[1][r]);
+}
+
+// Stash of a wave-local layer -> its rows of an LDS tile.
+template <class C>
+__device__ __forceinline__ void restore_rows(const f32x4 (&keep)[2][2], float* out, int rt) {
+    restore_tile<C>(keep[0], out, rt);
+    restore_tile<C>(keep[1], out, rt + 4);
 }
 
 // Head forward (one 16-wide tile per 16 rows; 4 waves): out[b][n] = epi(sum_k X[b][k] W[n][k]), n < N.  EXP: exp().
@@ -438,7 +505,7 @@ __device__ __forceinline__ void fwd_head(const float* X, const float* W, float* 
     const f32x4 acc = mm_fwd1<C::KS_H>(X + mul24(16 * rt + c, C::ST), W + mul24(min(c, N - 1), C::KS_H), q);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (c < N) out[mul24(16 * rt + 4 * q, C::SS) + r * C::SS + c] = EXP ? expf(acc[r]) : acc[r];
+        if (c < N) out[mul24(16 * rt + 4 * q, C::SS) + r * C::SS + c] = EXP ? fexp(acc[r]) : acc[r];
 }
 
 // Hidden-layer dgrad: out[b][k] = mask(h[b][k]) * sum_n dY[b][n] W[n][k] for k < KB, 0 beyond.
@@ -685,8 +752,7 @@ __device__ __forceinline__ void store_xu(const float (&xu)[C::NXU], float* tile)
 template <class C>
 __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* arena = lds;
-    float* T0 = arena + C::ARENA;
+    float* T0 = lds;
     float* T1 = T0 + C::TILE;
     float* T2 = T1 + C::TILE;
     float* T3 = T2 + C::TILE;          // [x | u | 1] of the current batch, resident for the whole step
@@ -695,10 +761,17 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     float* sV = sG + C::SMALL;         // v = exp(logv), then dLoss/dlogv
     float* sL = sV + C::SMALL;         // l = exp(logl), then dLoss/dlogl
     float* sZ = sL + C::SMALL;         // eps, then z (with its constant-1 column), then the head-gradient stage
-    float* sO = T0;                    // dLoss/df (decoder head delta), D3..BF3
+    float* sO = sZ + C::SMALL;         // dLoss/df (decoder head delta), forward stage..BF3
+    float* arena = sO + C::SMALL;      // parameters, last: anything read past the end of a tile is still a finite LDS word
     float* sD = T1;                    // dLoss/dz from the decoder, BF1..E
     float* stF0 = T1 + C::SMALL;       // gradient stage of the decoder's first layer, BF1..E
     float* red = stF0 + C::H * C::KS_F0;   // 8 loss partials, E..G3
+    // hand-off flags of the forward stage: pad column of T3, rows 0..11
+    float* flagV = T3 + C::KIN + 1;                  // [rt]: v rows of tile rt are in sV, and T4's rows rt are free
+    float* flagG = flagV + 4 * C::ST;                // [rt]: the g chain has read its last word of T0's rows rt
+    float* flagZ = flagV + 8 * C::ST;                // [rt]: z rows of tile rt are in sZ
+    float* flagL = flagV + 12 * C::ST;               // [rt]: h1l rows of tile rt are in T1
+    static_assert(C::KIN + 1 < C::ST, "the input tile has a pad column for the flags");
 
     constexpr int ST = C::ST, SS = C::SS, H = C::H, DD = C::DD, DL = C::DL, M = C::M;
     constexpr int KS_H = C::KS_H, KS_E0 = C::KS_E0, KS_L0 = C::KS_L0, KS_F0 = C::KS_F0;
@@ -799,91 +872,80 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         const int next_row = min(max(idxp[(size_t)min(s + 1, A.n_steps - 1) * FT_B + (tid >> 3)], 0), last_row);
         lds_barrier(); STAMP(1);
 
-        // ---- F1: h1g -> T0, h1v -> T1 (one pass over the shared input)
-        f32x4 k1g[2], k1v[2], k2g[2], k2v[2], k1l[2], k2l[2];
-        {
-            const float* const W[2] = {arena + C::off_of(L_G0), arena + C::off_of(L_V0)};
-            float* const out[2] = {T0, T1};
-            f32x4 keep[2][2];
-            fwd_hidden<C, 2, KS_E0>(T3, ST, W, out, slope, w, keep);
-            k1g[0] = keep[0][0]; k1g[1] = keep[0][1]; k1v[0] = keep[1][0]; k1v[1] = keep[1][1];
-        }
-        lds_barrier(); STAMP(2);
-        // ---- F2: h2g -> T2, h2v -> T4; next batch's rows start to arrive in registers
-#ifndef FT_ABL_NOXU            // timing experiment only: every step re-uses the first batch
-        load_xu<C>(xu, next_row, xd, ud);
-#endif
-        {
-            const int ln = opaque_lane();
-            const float* const Wg[1] = {arena + C::off_of(L_G1)};
-            const float* const Wv[1] = {arena + C::off_of(L_V1)};
-            f32x4 kg[1][2], kv[1][2];
-            STAMPW(0);
-            fwd_product<C, 1, KS_H>(T0, ST, Wg, w, ln, kg, NoFill());
-            STAMPW(1);
-            // epilogue of the g tile pair row by row between the MFMAs of the v product
-            fwd_product<C, 1, KS_H>(T1, ST, Wv, w, ln, kv, [&](int t) __attribute__((always_inline)) {
-                if (t < 4) fwd_epilogue_row<C>(kg[0], t, T2, slope, w, ln);
-            });
-            STAMPW(2);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(kv[0], r, T4, slope, w, ln);
-            STAMPW(3);
-            k2g[0] = kg[0][0]; k2g[1] = kg[0][1];
-            k2v[0] = kv[0][0]; k2v[1] = kv[0][1];
-        }
-        lds_barrier(); STAMP(3); STAMPW(4);
-        // ---- F3: heads g -> sG (waves 0-3), v = exp(logv) -> sV (waves 4-7); prior layer 1: h1l -> T0
-        if (w < 4) fwd_head<C, DL, false>(T2, arena + C::off_of(L_G2), sG, rt);
-        else fwd_head<C, DL, true>(T4, arena + C::off_of(L_V2), sV, rt);
-        if constexpr (C::HAS_U) {
-            const float* const W[1] = {arena + C::off_of(L_L0)};
-            float* const out[1] = {T0};
-            f32x4 keep[1][2];
-            fwd_hidden<C, 1, KS_L0>(T3 + C::UOFF, ST, W, out, slope, w, keep);
-            k1l[0] = keep[0][0]; k1l[1] = keep[0][1];
-        }
-        lds_barrier(); STAMP(4);
-        // ---- F4: prior layer 2: h2l -> T1; reparameterisation z = g + eps * sqrt(v) -> sZ (nets.py:301-304)
-        if constexpr (C::HAS_U) {
-            const float* const W[1] = {arena + C::off_of(L_L1)};
-            float* const out[1] = {T1};
-            f32x4 keep[1][2];
-            fwd_hidden<C, 1, KS_H>(T0, ST, W, out, slope, w, keep);
-            k2l[0] = keep[0][0]; k2l[1] = keep[0][1];
-        }
-        for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
-            const int b = e / SS, k = e - b * SS;
-            float zz = k == DL ? 1.f : 0.f;
-            if (k < DL) {
-                zz = sZ[e] * sqrtf(sV[e]) + sG[e];
-                if (A.z_out && s == A.n_steps - 1) A.z_out[((size_t)model * FT_B + b) * DL + k] = zz;
-                if (A.z_steps) A.z_steps[(((size_t)model * A.n_steps_total + A.step_begin + s) * FT_B + b) * DL + k] = zz;
-            }
-            sZ[e] = zz;
-        }
-        lds_barrier(); STAMP(5);
-        // ---- F5: prior head l = exp(logl) -> sL (waves 0-3); decoder layer 1: h1f -> T2
-        if constexpr (C::HAS_U) if (w < 4) fwd_head<C, DL, true>(T1, arena + C::off_of(L_L2), sL, rt);
-        {
-            const float* const W[1] = {arena + C::off_of(L_F0)};
-            float* const out[1] = {T2};
-            f32x4 keep[1][2];
-            fwd_hidden<C, 1, KS_F0>(sZ, SS, W, out, slope, w, keep);
-        }
-        lds_barrier(); STAMP(6);
-        // ---- D2: h2f -> T4
-        {
-            const float* const W[1] = {arena + C::off_of(L_F1)};
-            float* const out[1] = {T4};
-            f32x4 keep[1][2];
-            fwd_hidden<C, 1, KS_H>(T2, ST, W, out, slope, w, keep);
-        }
-        lds_barrier(); STAMP(7);
-        // ---- D3: decoder head f, log p(x|z) and dLoss/df -> sO (waves 0-3); latent log-densities
-        //          log q(z|x,u), log p(z|u) (nets.py:306-314) on waves 4-7
+        // ---- forward stage, wave-local chains (no workgroup barrier inside).  Row tile rt = w & 3 is owned by the
+        // two waves of one SIMD: wave rt runs the g chain and then the decoder, wave rt + 4 the logv chain and then the
+        // prior.  The chains of a pair are independent instruction streams, so one wave's epilogues and LDS round
+        // trips run under the other's MFMAs.  Tiles (rows rt only): g: T3 -> T0 -> T2 -> sG; v: T3 -> T1 -> T4 -> sV;
+        // prior: u(T3) -> T1 -> T0 -> sL; decoder: sZ -> T2 -> T4 -> sO.  Hand-offs between the pair: flags.
+        // stash (48 registers a lane): waves 0-3 hold h1g, h2g and -- read back from the partner's tile at the end of the
+        // stage, so that both waves of a pair carry the same load -- h1l; waves 4-7 hold h1v, h2v, h2l
+        f32x4 s1[2][2], s2[2][2], s3[2][2];
         float lsum = 0.f;
+        const int step_no = s + 1;
+#ifndef FT_ABL_NOXU            // timing experiment only: every step re-uses the first batch
+        load_xu<C>(xu, next_row, xd, ud);                  // next batch's rows start to arrive in registers
+#endif
+#ifdef FT_ABL_NOFWD            // timing experiment only
+        if (A.n_steps < 0)
+#endif
         if (w < 4) {
+            STAMPW(0);
+            fwd_rows<C, KS_E0>(T3, ST, arena + C::off_of(L_G0), T0, slope, rt, s1);
+            STAMPW(1);
+#ifdef FT_PROF
+            {
+                const int ln = opaque_lane();
+                fwd_rows_product<C, KS_H>(T0, ST, arena + C::off_of(L_G1), rt, ln, s2, NoFill());
+                STAMPW(9);
+                for (int p = 0; p < 2; ++p) for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(s2[p], r, T2, slope, rt + 4 * p, ln);
+            }
+#else
+            fwd_rows<C, KS_H>(T0, ST, arena + C::off_of(L_G1), T2, slope, rt, s2);
+#endif
+            STAMPW(2);
+            if constexpr (C::HAS_U) flag_raise(flagG + rt * ST, step_no);          // T0's rows rt may be overwritten (h2l)
+            fwd_head<C, DL, false>(T2, arena + C::off_of(L_G2), sG, rt);
+            STAMPW(3);
+            flag_wait(flagV + rt * ST, step_no);
+            STAMPW(4);
+            // reparameterisation z = g + eps * sqrt(v) (nets.py:301-304), rows of this tile: lane = (row, a quarter of the
+            // SS columns); all loads first, v_sqrt_f32 (1 ulp)
+            {
+                constexpr int QC = SS / 4;
+                static_assert(SS % 4 == 0, "row-tensor stride is a multiple of 4");
+                const int ln = opaque_lane();
+                const int b = 16 * rt + (ln >> 2), k0 = (ln & 3) * QC, i0 = b * SS + k0;
+                float ev[QC], vv[QC], gv[QC];
+#pragma unroll
+                for (int j = 0; j < QC; ++j) { ev[j] = sZ[i0 + j]; vv[j] = sV[i0 + j]; gv[j] = sG[i0 + j]; }
+#pragma unroll
+                for (int j = 0; j < QC; ++j) {
+                    const int k = k0 + j;
+                    float zz = k == DL ? 1.f : 0.f;
+                    if (k < DL) zz = ev[j] * __builtin_amdgcn_sqrtf(vv[j]) + gv[j];
+                    ev[j] = zz;
+                    sZ[i0 + j] = zz;
+                }
+                if (A.z_out && s == A.n_steps - 1) {
+#pragma unroll
+                    for (int j = 0; j < QC; ++j) if (k0 + j < DL) A.z_out[((size_t)model * FT_B + b) * DL + k0 + j] = ev[j];
+                }
+                if (A.z_steps) {
+#pragma unroll
+                    for (int j = 0; j < QC; ++j)
+                        if (k0 + j < DL) A.z_steps[(((size_t)model * A.n_steps_total + A.step_begin + s) * FT_B + b) * DL + k0 + j] = ev[j];
+                }
+            }
+            flag_raise(flagZ + rt * ST, step_no);
+            STAMPW(5);
+            {
+                f32x4 keep[2][2];
+                fwd_rows<C, KS_F0>(sZ, SS, arena + C::off_of(L_F0), T2, slope, rt, keep);      // h1f
+                STAMPW(6);
+                fwd_rows<C, KS_H>(T2, ST, arena + C::off_of(L_F1), T4, slope, rt, keep);       // h2f
+                STAMPW(7);
+            }
+            // decoder head f, log p(x|z) and dLoss/df -> sO
             const f32x4 acc = mm_fwd1<KS_H>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F2) + min(c, DD - 1) * KS_H, q);
             const float inv_dv = 1.f / A.decoder_var, logdv = logf(A.decoder_var);
 #pragma unroll
@@ -897,9 +959,51 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 }
                 if (c < SS) sO[row * SS + c] = dout;
             }
+            STAMPW(8);
+            if constexpr (C::HAS_U) {          // take over the partner's h1l (same register layout as a stash)
+                flag_wait(flagL + rt * ST, step_no);
+                const int ln = opaque_lane();
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col0 = 32 * p + 2 * (ln & 15);
+                        const f32x2 h = ld2(T1 + mul24(16 * rt + 4 * (ln >> 4), ST) + r * ST + min(col0, ST - 2));
+                        s3[p][0][r] = h.x;
+                        s3[p][1][r] = h.y;
+                    }
+            }
         } else {
-            for (int e = tid - FT_THREADS / 2; e < FT_B * DL; e += FT_THREADS / 2) {
-                const int b = e / DL, k = e - b * DL, i = b * SS + k;
+#ifdef FT_DEPHASE
+            __builtin_amdgcn_s_sleep(FT_DEPHASE);          // start half a layer behind the partner wave
+#endif
+            STAMPW(0);
+            fwd_rows<C, KS_E0>(T3, ST, arena + C::off_of(L_V0), T1, slope, rt, s1);
+            STAMPW(1);
+            fwd_rows<C, KS_H>(T1, ST, arena + C::off_of(L_V1), T4, slope, rt, s2);
+            STAMPW(2);
+            fwd_head<C, DL, true>(T4, arena + C::off_of(L_V2), sV, rt);
+            flag_raise(flagV + rt * ST, step_no);
+            STAMPW(3);
+            if constexpr (C::HAS_U) {
+                {
+                    f32x4 keep[2][2];
+                    fwd_rows<C, KS_L0>(T3 + C::UOFF, ST, arena + C::off_of(L_L0), T1, slope, rt, keep);
+                }
+                flag_raise(flagL + rt * ST, step_no);
+                STAMPW(4);
+                flag_wait(flagG + rt * ST, step_no);
+                fwd_rows<C, KS_H>(T1, ST, arena + C::off_of(L_L1), T0, slope, rt, s3);
+                STAMPW(5);
+                fwd_head<C, DL, true>(T0, arena + C::off_of(L_L2), sL, rt);
+                STAMPW(6);
+            }
+            flag_wait(flagZ + rt * ST, step_no);
+            STAMPW(7);
+            // latent log-densities log q(z|x,u), log p(z|u) (nets.py:306-314), rows of this tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own sV / sL rows
+            for (int e = lane; e < 16 * DL; e += 64) {
+                const int b = 16 * rt + e / DL, k = e % DL, i = b * SS + k;
                 const float zz = sZ[i], vv = sV[i], dq = zz - sG[i];
                 const float lqc = -0.5f * (LOG2PI_F + flog(vv) + dq * dq * __builtin_amdgcn_rcpf(vv));
                 float lp = -0.5f * (LOG2PI_F + zz * zz);
@@ -908,6 +1012,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             }
         }
         lds_barrier(); STAMP(8);
+#ifdef FT_ABL_NOBWD            // timing experiment only
+        if (A.n_steps < 0) {
+#endif
 
         // ---- BF3: d2f -> T1; decoder-head gradient -> T0 + STG_F2 (waves 0-3)
         dgrad_hidden<C, SS, DD, KS_H, H>(sO, SS, arena + C::off_of(L_F2), T4, T1, slope, w);
@@ -949,8 +1056,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             if constexpr (C::HAS_U) sL[e] = dl;
         }
         ADAM(L_F0, stF0);
-        restore_tile<C>(k2g, T2, w);
-        restore_tile<C>(k1g, T4, w);
+        if (w < 4) { restore_rows<C>(s2, T2, rt); restore_rows<C>(s1, T4, rt); }
         {   // loss reduction (deterministic): wave shuffle -> 8 partials -> thread 0 (next phase)
             float v = lsum;
 #pragma unroll
@@ -964,48 +1070,51 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             const float t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
             A.loss_out[(size_t)model * A.n_steps_total + A.step_begin + s] = -t * wB;
         }
-        dgrad_hidden_reg<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), k2g, T0, slope, w);
+        dgrad_hidden<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), T2, T0, slope, w);
         if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
         lds_barrier(); STAMP(13);
         // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
-        stagger(w, LAMBDA { dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), k1g, T2, slope, w); },
+        stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), T4, T2, slope, w); },
                 LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_G2, sZ); });
         lds_barrier(); STAMP(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
         WGRAD_ADAM(H, KS_E0, C::KIN, T2, ST, T3, ST, T0, L_G1, T1);
-        restore_tile<C>(k2v, T4, w);
+        if (w >= 4) restore_rows<C>(s2, T4, rt);
         lds_barrier(); STAMP(15);
 
         // ---- V3: d2v -> T1; head gradient -> sZ; Adam(G0); h1v -> T2
         stagger(w, LAMBDA {
-                    dgrad_hidden_reg<C, SS, DL, KS_H, H>(sV, SS, arena + C::off_of(L_V2), k2v, T1, slope, w);
+                    dgrad_hidden<C, SS, DL, KS_H, H>(sV, SS, arena + C::off_of(L_V2), T4, T1, slope, w);
                     if (w < 4) wgrad_tile<C, DL, KS_H, H>(sV, SS, T4, ST, sZ, 0, w);
-                }, LAMBDA { ADAM(L_G0, T0); restore_tile<C>(k1v, T2, w); });
+                }, LAMBDA { ADAM(L_G0, T0); if (w >= 4) restore_rows<C>(s1, T2, rt); });
         lds_barrier(); STAMP(16);
         // ---- V2: d1v -> T4; layer-2 gradient -> T0; Adam(V2)
-        stagger(w, LAMBDA { dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), k1v, T4, slope, w); },
+        stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), T2, T4, slope, w); },
                 LAMBDA { wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w); ADAM(L_V2, sZ); });
         lds_barrier(); STAMP(17);
         // ---- V1: layer-1 gradient -> T1; Adam(V1); h2l -> T2
         WGRAD_ADAM(H, KS_E0, C::KIN, T4, ST, T3, ST, T1, L_V1, T0);
-        if constexpr (C::HAS_U) restore_tile<C>(k2l, T2, w);
+        if constexpr (C::HAS_U) { if (w >= 4) restore_rows<C>(s3, T2, rt); }
         lds_barrier(); STAMP(18);
 
         if constexpr (C::HAS_U) {
             // ---- L3: d2l -> T0; head gradient -> sZ; Adam(V0); h1l -> T4
             stagger(w, LAMBDA {
-                        dgrad_hidden_reg<C, SS, DL, KS_H, H>(sL, SS, arena + C::off_of(L_L2), k2l, T0, slope, w);
+                        dgrad_hidden<C, SS, DL, KS_H, H>(sL, SS, arena + C::off_of(L_L2), T2, T0, slope, w);
                         if (w < 4) wgrad_tile<C, DL, KS_H, H>(sL, SS, T2, ST, sZ, 0, w);
-                    }, LAMBDA { ADAM(L_V0, T1); restore_tile<C>(k1l, T4, w); });
+                    }, LAMBDA { ADAM(L_V0, T1); if (w < 4) restore_rows<C>(s3, T4, rt); });
             lds_barrier(); STAMP(19);
             // ---- L2: d1l -> T2; layer-2 gradient -> T1; Adam(L2)
-            stagger(w, LAMBDA { dgrad_hidden_reg<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), k1l, T2, slope, w); },
+            stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), T4, T2, slope, w); },
                     LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_L2, sZ); });
             lds_barrier(); STAMP(20);
             // ---- L1: layer-1 gradient -> T0; Adam(L1)
             WGRAD_ADAM(H, KS_L0, M, T2, ST, T3 + C::UOFF, ST, T0, L_L1, T1);
             lds_barrier(); STAMP(21);
         }
+#ifdef FT_ABL_NOBWD
+        }
+#endif
     }
     // Adam of the last step's last layer
     if (A.n_steps > 0) {

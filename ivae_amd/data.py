@@ -7,14 +7,14 @@ inputs are bit-exact").  Written from the specification of SURVEY.md §3.4 / §8
   get the 25th-percentile condition threshold, then rejection sampling of column-normalised U(0,2)-1
   matrices  ->  [noise]                                              (data/data.py:134-197, 69-131, 200-304)
 
-The torch ``Dataset`` wrappers keep the reference's constructor signatures and ``__getitem__`` tuples
-(data/data.py:318-413).  No acceleration here: this is plumbing either side of the hot path.
+``ResidentDataset`` holds a dataset as three whole tensors for the device-resident loops (the reference's torch
+``Dataset`` classes feed a DataLoader, which those loops do not use).  No acceleration here: this is plumbing either
+side of the hot path.
 """
 import os
 
 import numpy as np
 import torch
-from torch.utils.data import Dataset
 
 
 def to_one_hot(x, m=None):
@@ -198,79 +198,42 @@ def save_data(path, *args, **kwargs):
     print(' ... done')
 
 
-class SyntheticDataset(Dataset):
-    """data.py:318-378."""
+class ResidentDataset:
+    """The observations x, auxiliary variables u and true sources s of one dataset as three whole tensors.
 
-    def __init__(self, root, nps, ns, dl, dd, nl, s, p, a, uncentered=False, noisy=False, centers=None, double=False,
-                 one_hot_labels=True):
-        self.root = root
-        data = self.load_tcl_data(root, nps, ns, dl, dd, nl, s, p, a, uncentered, noisy, centers, one_hot_labels)
-        self.data = data
-        self.s = torch.from_numpy(data['s'])
-        self.x = torch.from_numpy(data['x'])
-        self.u = torch.from_numpy(data['u'])
-        self.l = data['L']
-        self.m = data['m']
-        self.len = self.x.shape[0]
-        self.latent_dim = self.s.shape[1]
-        self.aux_dim = self.u.shape[1]
-        self.data_dim = self.x.shape[1]
-        self.prior, self.activation, self.seed, self.n_layers = p, a, s, nl
-        self.uncentered, self.noisy, self.double, self.one_hot_labels = uncentered, noisy, double, one_hot_labels
+    This is all the training loops here need of a dataset: they keep it resident in HBM and form batches on the device
+    from an index permutation, so there is no per-sample `__getitem__`, no DataLoader and no worker processes (the
+    reference's torch Dataset classes, data/data.py:318-413, exist to feed a DataLoader)."""
 
-    def get_dims(self):
-        return self.data_dim, self.latent_dim, self.aux_dim
+    def __init__(self, x, u, s=None):
+        as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        self.x, self.u = as_t(x), as_t(u)
+        self.s = as_t(s) if s is not None else self.x        # no ground truth: scores are taken against x
+        if not (self.x.shape[0] == self.u.shape[0] == self.s.shape[0]):
+            raise ValueError('x, u and s hold different numbers of samples')
 
-    def __len__(self):
-        return self.len
-
-    def __getitem__(self, index):
-        if not self.double:
-            return self.x[index], self.u[index], self.s[index]
-        index2 = np.random.choice(range(len(self)))
-        return self.x[index], self.x[index2], self.u[index], self.s[index]
-
-    @staticmethod
-    def load_tcl_data(root, nps, ns, dl, dd, nl, s, p, a, uncentered, noisy, centers, one_hot_labels):
+    @classmethod
+    def cached(cls, root, nps, ns, dl, dd, nl, s, p, a, uncentered=False, noisy=False):
+        """The dataset `configs/*.yaml` names (keys nps ns dl dd nl s p act), generated once by `generate_data` and
+        kept as `<root>tcl_<...>.npz` under the reference's file name and keys, so either code base reads the other's
+        cache (data/data.py:357-372).  `s = None` (no seed) always regenerates."""
         path = dataset_path(root, nps, ns, dl, dd, nl, s, p, a, uncentered, noisy)
-        if not os.path.exists(path) or s is None:
+        if s is None or not os.path.exists(path):
             save_data(path, n_per_seg=nps, n_seg=ns, d_sources=dl, d_data=dd, n_layers=nl, prior=p, activation=a,
-                      seed=s, batch_size=0, uncentered=uncentered, noisy=noisy, centers=centers, repeat_linearity=True,
-                      one_hot_labels=one_hot_labels)
+                      seed=s, uncentered=uncentered, noisy=noisy, repeat_linearity=True, one_hot_labels=True)
         print('loading data from {}'.format(path))
-        return np.load(path)
-
-    def get_test_sample(self, batch_size, seed=None):
-        if seed is not None:
-            np.random.seed(seed)
-        idx = np.random.randint(max(0, self.len - batch_size))
-        return self.x[idx:idx + batch_size], self.u[idx:idx + batch_size], self.s[idx:idx + batch_size]
-
-
-class CustomSyntheticDataset(Dataset):
-    """data.py:381-413."""
-
-    def __init__(self, X, U, S=None, device='cpu'):
-        self.device = device
-        self.x = torch.from_numpy(X).to(self.device)
-        self.u = torch.from_numpy(U).to(self.device)
-        self.s = torch.from_numpy(S).to(self.device) if S is not None else self.x
-        self.len = self.x.shape[0]
-        self.latent_dim = self.s.shape[1]
-        self.aux_dim = self.u.shape[1]
-        self.data_dim = self.x.shape[1]
-        self.nps = int(self.len / self.aux_dim)
-        print('data loaded on {}'.format(self.x.device))
-
-    def get_dims(self):
-        return self.data_dim, self.latent_dim, self.aux_dim
+        with np.load(path) as z:
+            out = cls(z['x'], z['u'], z['s'])
+            out.mixing_scales, out.segment_means = z['L'], z['m']
+        return out
 
     def __len__(self):
-        return self.len
+        return self.x.shape[0]
 
-    def __getitem__(self, index):
-        return self.x[index], self.u[index], self.s[index]
+    def get_dims(self):
+        """(data_dim, latent_dim, aux_dim)"""
+        return self.x.shape[1], self.s.shape[1], self.u.shape[1]
 
-    def get_metadata(self):
-        return {'nps': self.nps, 'ns': self.aux_dim, 'n': self.len, 'latent_dim': self.latent_dim,
-                'data_dim': self.data_dim, 'aux_dim': self.aux_dim}
+    def to(self, device):
+        out = ResidentDataset(self.x.to(device), self.u.to(device), self.s.to(device) if self.s is not self.x else None)
+        return out

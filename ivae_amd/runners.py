@@ -23,7 +23,7 @@ from scipy.optimize import linear_sum_assignment
 from torch import optim
 
 from . import ops
-from .data import CustomSyntheticDataset, SyntheticDataset
+from .data import ResidentDataset
 from .mcc import corr_matrix_gpu, mean_corr_coef as mcc
 from .nets import VAE, cleanIVAE, cleanVAE, iVAE
 from .optim import FusedAdam
@@ -73,8 +73,8 @@ def runner(args, config, *, replay=None, trace=None):
     if config.gamma > 0:
         raise NotImplementedError('FactorVAE discriminator branch (gamma > 0) is outside the fused hot path; every '
                                   'shipped config has gamma: 0')
-    dset = SyntheticDataset(args.data_path, config.nps, config.ns, config.dl, config.dd, config.nl, config.s, config.p,
-                            config.act, uncentered=config.uncentered, noisy=config.noisy, double=False)
+    dset = ResidentDataset.cached(args.data_path, config.nps, config.ns, config.dl, config.dd, config.nl, config.s,
+                                  config.p, config.act, uncentered=config.uncentered, noisy=config.noisy)
     d_data, d_latent, d_aux = dset.get_dims()
     X, U, S = dset.x.to(device), dset.u.to(device), dset.s.to(device)
     N, B = len(dset), config.batch_size
@@ -306,7 +306,7 @@ def IVAE_wrapper(X, U, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers
         np.random.seed(seed)
     device = torch.device('cuda')
     print('training on {}'.format(torch.cuda.get_device_name(device)))
-    dset = CustomSyntheticDataset(X, U, S, 'cpu')
+    dset = ResidentDataset(X, U, S)
     data_dim, latent_dim, aux_dim = dset.get_dims()
     if inference_dim is not None:
         latent_dim = inference_dim
@@ -329,7 +329,7 @@ def VAE_wrapper(X, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers=3, 
         np.random.seed(seed)
     device = torch.device('cuda')
     print('training on {}'.format(torch.cuda.get_device_name(device)))
-    dset = CustomSyntheticDataset(X, X, S, 'cpu')
+    dset = ResidentDataset(X, X, S)
     data_dim, latent_dim, _ = dset.get_dims()
     if inference_dim is not None:
         latent_dim = inference_dim

@@ -30,13 +30,14 @@ def test_generator_matches_reference(i):
 
 def test_dataset_cache_name_and_keys(tmp_path):
     root = str(tmp_path) + "/"
-    ds = D.SyntheticDataset(root, 20, 3, 2, 2, 3, 1, 'gauss', 'xtanh')
-    assert os.path.exists(root + "tcl_20_3_2_2_3_1_gauss_xtanh.npz")
+    ds = D.ResidentDataset.cached(root, 20, 3, 2, 2, 3, 1, 'gauss', 'xtanh')
+    assert os.path.exists(root + "tcl_20_3_2_2_3_1_gauss_xtanh.npz")       # the reference's cache name (data.py:358-364)
     z = np.load(root + "tcl_20_3_2_2_3_1_gauss_xtanh.npz")
-    assert sorted(z.files) == ["L", "m", "s", "u", "x"]
+    assert sorted(z.files) == ["L", "m", "s", "u", "x"]                     # ... and keys (data.py:314)
     assert ds.get_dims() == (2, 2, 3) and len(ds) == 60
-    x, u, s = ds[5]
-    assert x.shape == (2,) and u.shape == (3,) and float(u.sum()) == 1.0
+    assert ds.x.shape == (60, 2) and ds.u.shape == (60, 3) and bool((ds.u.sum(1) == 1).all())
+    again = D.ResidentDataset.cached(root, 20, 3, 2, 2, 3, 1, 'gauss', 'xtanh')     # second call reads the cache
+    assert bool((again.x == ds.x).all())
     assert D.dataset_path("r/", 1, 2, 3, 4, 5, 6, 'lap', 'lrelu', True, True) == "r/tcl_1_2_3_4_5_6_lap_lrelu_u_noisy.npz"
-    cd = D.CustomSyntheticDataset(ds.x.numpy(), ds.u.numpy(), ds.s.numpy())
-    assert cd.get_metadata()["nps"] == 20
+    cd = D.ResidentDataset(ds.x.numpy(), ds.u.numpy())                      # no ground truth: s falls back to x
+    assert cd.get_dims() == (2, 2, 3) and cd.s is cd.x

@@ -344,16 +344,16 @@ def make_runner_traces():
                         return R.runner(args, config)
 
                     key = f"{name}.s{seed}"
-                    if seed == seeds[0]:
+                    if True:
                         # How far does the REFERENCE move when its initial parameters move by 1e-6 relative (same batch
                         # order: the shuffle is seeded by the per-step noise seeds; same noise)?  Hundreds of Adam steps
                         # amplify round-off; the replay test holds ivae_amd to a multiple of this measured spread.
-                        sens = [run(k) for k in (1, 2)]
+                        sens = [run(k) for k in (1, 2, 3, 4)]
                         out[key + ".sens_loss_hist"] = np.array([r_[1][0] for r_ in sens], np.float64)
                         out[key + ".sens_perf_hist"] = np.array([r_[2][0] for r_ in sens], np.float64)
                         out[key + ".sens_perf"] = np.array([r_[0][0] for r_ in sens], np.float64)
                     perfs, loss_hists, perf_hists = run(0)
-                    if seed == seeds[0]:
+                    if True:
                         print(f"  sensitivity {key}: perf_hist {out[key + '.sens_perf_hist'].tolist()} perf {out[key + '.sens_perf'].tolist()}")
                     B = cfg["batch_size"]
                     nb = rec.N // B

@@ -13,8 +13,8 @@ import torch
 from ivae_amd import _lib, ops
 from ivae_amd.trainer import FusedPackedTrainer
 
-LABELS = ["P0 adam(last) + XU/eps -> LDS", "F1 enc L1 (g,v)", "F2 enc L2 (g,v)", "F3 heads g,v + prior L1", "F4 prior L2 + z",
-          "F5 prior head + dec L1", "D2 dec L2", "D3 dec head + loss", "BF3 dgrad+wgrad head", "BF2 dgrad+wgrad+adam",
+LABELS = ["P0 adam(last) + XU/eps -> LDS", "FWD wave-local chains (g|v, decoder|prior)", "-", "-", "-",
+          "-", "-", "-", "BF3 dgrad+wgrad head", "BF2 dgrad+wgrad+adam",
           "BF1 dz | wgrad + adam", "E deltas + adam + restore", "G3", "G2", "G1", "V3", "V2", "V1", "L3", "L2", "L1"]
 NSEG = len(LABELS)
 
@@ -40,10 +40,14 @@ tot = mean.sum()
 print(f"models={M}  cycles/step (wave 0 of model 0): {tot:.0f}")
 for l, c in zip(LABELS, mean):
     print(f"  {l:28s} {c:9.0f}  {100*c/tot:5.1f}%")
-# sub-phase stamps of the F2 phase: wave 0 (slots 32..) and wave 4 (slots 48..): 0 = before product g, 1 = after its
-# MFMAs, 2 = after product v (+ epilogue g in its shadow), 3 = after epilogue v, 4 = after the barrier
+# forward-stage timeline of wave 0 (g chain, decoder; slots 32..) and wave 4 (logv chain, prior; slots 48..), cycles from
+# the stage's first stamp of wave 0
 raw = buf.cpu().numpy().reshape(steps, 64).astype(np.float64)[6:]
-for wv, base in (("wave0", 32), ("wave4", 48)):
-    d = raw[:, base:base + 5] - raw[:, base:base + 1]
-    print(wv, "F2 sub-stamps (cycles from the first):", np.round(d.mean(0)).astype(int).tolist())
-print("F2 phase start (STAMP 2) -> first sub-stamp, wave0:", int(np.round((raw[:, 32] - raw[:, 2]).mean())))
+names0 = ["start", "g L0", "g L1", "g head", "wait v", "z", "dec L0", "dec L1", "dec head+dO"]
+names4 = ["start", "v L0", "v L1", "v head", "prior L0", "prior L1 (+wait g)", "prior head", "wait z"]
+for wv, base, names in (("wave0", 32, names0), ("wave4", 48, names4)):
+    d = raw[:, base:base + len(names)] - raw[:, 32:33]
+    m = d.mean(0)
+    print(wv, " ".join(f"{n}@{int(v)}(+{int(v - (m[i - 1] if i else 0))})" for i, (n, v) in enumerate(zip(names, m))))
+print("wave0 g L1: product took", int((raw[:, 32 + 9] - raw[:, 32 + 1]).mean()), "epilogue", int((raw[:, 32 + 2] - raw[:, 32 + 9]).mean()))
+print("stage barrier released (STAMP 8) @", int((raw[:, 8] - raw[:, 32]).mean()))
