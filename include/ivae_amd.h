@@ -146,12 +146,14 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
  *   eps_steps (n_steps, n_models, batch, latent_dim)
  * and writes loss_out (n_steps, n_models) and z_steps (n_steps, n_models, batch, latent_dim).
  * params / exp_avg / exp_avg_sq (n_models, P) in/out; grads (n_models, P): scratch for the flat gradient;
- * step0 = Adam steps already taken; lr and the loss weights are constant over the call. */
+ * step0 = Adam steps already taken; lr and the loss weights are constant over the call.
+ * model_lr: NULL, or n_models learning rates in HOST memory that replace `lr` model by model (packed seeds of one
+ * `main.py --n-sims K` run: each has its own ReduceLROnPlateau, runners/ivae.py:39,113-114); read before the call returns. */
 int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef,
                          float* params, float* exp_avg, float* exp_avg_sq,
                          const float* x_steps, const float* u_steps, const float* eps_steps,
                          int32_t n_steps, int64_t step0,
-                         double lr, double beta1, double beta2, double adam_eps,
+                         double lr, const double* model_lr, double beta1, double beta2, double adam_eps,
                          float* loss_out, float* z_steps, float* grads,
                          void* workspace, size_t workspace_bytes, void* stream);
 

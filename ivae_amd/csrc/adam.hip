@@ -34,3 +34,42 @@ hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, 
                        (float)(1.0 - b2), neg_step, bc2_sqrt, (float)eps);
     return hipGetLastError();
 }
+
+// Packed models with their own learning rates (every run of a packed seed sweep has its own ReduceLROnPlateau,
+// runners/ivae.py:39,113-114): blockIdx.y = model, its step size travels in the kernel arguments.
+#define ADAM_MODELS_PER_LAUNCH 256
+struct AdamModelSteps { float neg_step[ADAM_MODELS_PER_LAUNCH]; };
+
+__global__ __launch_bounds__(256) void k_adam_models(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                     const float* __restrict__ g, int64_t n_per_model, float w1, float b2,
+                                                     float w2, AdamModelSteps S, float bc2_sqrt, float eps) {
+    const int64_t base = (int64_t)blockIdx.y * n_per_model;
+    const float neg_step = S.neg_step[blockIdx.y];
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_per_model; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + j;
+        const float gi = g[i];
+        const float mi = m[i] + w1 * (gi - m[i]);
+        const float vi = v[i] * b2 + (w2 * gi) * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] + (neg_step * mi) / denom;
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+hipError_t launch_adam_models(float* p, float* m, float* v, const float* g, int64_t n_per_model, int n_models,
+                              const double* model_lr, double b1, double b2, double eps, int64_t step, hipStream_t st) {
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
+    int64_t bx = (n_per_model + 255) / 256;
+    if (bx > 64) bx = 64;
+    for (int m0 = 0; m0 < n_models; m0 += ADAM_MODELS_PER_LAUNCH) {
+        const int nm = n_models - m0 < ADAM_MODELS_PER_LAUNCH ? n_models - m0 : ADAM_MODELS_PER_LAUNCH;
+        AdamModelSteps S;
+        for (int i = 0; i < nm; ++i) S.neg_step[i] = (float)(-model_lr[m0 + i] / bc1);
+        const int64_t off = (int64_t)m0 * n_per_model;
+        hipLaunchKernelGGL(k_adam_models, dim3((unsigned)bx, (unsigned)nm), dim3(256), 0, st, p + off, m + off, v + off, g + off,
+                           n_per_model, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), S, bc2_sqrt, (float)eps);
+    }
+    return hipGetLastError();
+}

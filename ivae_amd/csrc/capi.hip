@@ -139,7 +139,7 @@ int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float
 
 int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
                          const float* x_steps, const float* u_steps, const float* eps_steps, int32_t n_steps,
-                         int64_t step0, double lr, double beta1, double beta2, double adam_eps, float* loss_out,
+                         int64_t step0, double lr, const double* model_lr, double beta1, double beta2, double adam_eps, float* loss_out,
                          float* z_steps, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = ivae_check_dims(dims);
     if (rc) return rc;
@@ -156,9 +156,15 @@ int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, float* para
                                z_steps + s * rows * dims->latent_dim, loss_out + (size_t)s * dims->n_models, grads, workspace,
                                workspace_bytes, stream);
         if (rc) return rc;
-        rc = ivae_adam_step(params, exp_avg, exp_avg_sq, grads, P * dims->n_models, lr, beta1, beta2, adam_eps, step0 + s + 1,
-                            stream);
-        if (rc) return rc;
+        if (model_lr) {
+            hipError_t e = launch_adam_models(params, exp_avg, exp_avg_sq, grads, P, dims->n_models, model_lr, beta1, beta2,
+                                              adam_eps, step0 + s + 1, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "ivae_elbo_adam_steps");
+        } else {
+            rc = ivae_adam_step(params, exp_avg, exp_avg_sq, grads, P * dims->n_models, lr, beta1, beta2, adam_eps, step0 + s + 1,
+                                stream);
+            if (rc) return rc;
+        }
     }
     return IVAE_OK;
 }

@@ -13,6 +13,8 @@ hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, con
 size_t pairwise_ws_floats(int n_rows, int n_cols, int d);
 hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1, double b2,
                        double eps, int64_t step, hipStream_t st);
+hipError_t launch_adam_models(float* p, float* m, float* v, const float* g, int64_t n_per_model, int n_models,
+                              const double* model_lr, double b1, double b2, double eps, int64_t step, hipStream_t st);
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st);
 size_t corr_ws_bytes(int64_t n, int d);
 hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int d, double* cc, hipStream_t st);

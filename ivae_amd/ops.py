@@ -144,7 +144,14 @@ def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, z_out=None):
 def elbo_adam_steps(shape, coef, params, exp_avg, exp_avg_sq, x_steps, u_steps, eps_steps, ws, step0, lr, beta1=0.9,
                     beta2=0.999, adam_eps=1e-8, n_models=1, z_out=None):
     """ivae_elbo_adam_steps: x_steps (n_steps, [n_models,] batch, data_dim) etc.; params and the Adam moments are
-    updated in place.  -> (loss (n_steps, n_models), z (like eps_steps))."""
+    updated in place.  `lr`: one learning rate, or a sequence of n_models of them (packed runs with their own
+    schedulers).  -> (loss (n_steps, n_models), z (like eps_steps))."""
+    if isinstance(lr, (list, tuple)):
+        if len(lr) != n_models:
+            raise ValueError("lr must be one value or one per model")
+        model_lr, lr = (C.c_double * n_models)(*[float(v) for v in lr]), float(lr[0])
+    else:
+        model_lr = None
     x_steps = _f32c(x_steps, "x_steps")
     eps_steps = _f32c(eps_steps, "eps_steps")
     u_steps = _f32c(u_steps, "u_steps") if shape.aux_dim > 0 else None
@@ -170,7 +177,7 @@ def elbo_adam_steps(shape, coef, params, exp_avg, exp_avg_sq, x_steps, u_steps, 
         grads = torch.empty_like(params)
         check(_lib.lib().ivae_elbo_adam_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
                                               _ptr(x_steps), _ptr(u_steps), _ptr(eps_steps), int(n_steps), int(step0),
-                                              float(lr), float(beta1), float(beta2), float(adam_eps), _ptr(loss), _ptr(z),
+                                              float(lr), model_lr, float(beta1), float(beta2), float(adam_eps), _ptr(loss), _ptr(z),
                                               _ptr(grads), _ptr(buf), buf.numel() * 4, _stream(dev)), "ivae_elbo_adam_steps")
     return loss, z
 

@@ -58,15 +58,73 @@ def _assignment_scores(cc_abs):
 
 
 # ------------------------------------------------------------------------------------------------ family A
+class _SeedPack:
+    """The `n_sims` models of one `main.py --n-sims K` run as ONE packed model set: their parameter arenas become the
+    rows of one (K, P) buffer (each model's `nn.Parameter`s stay views of its row, so `state_dict()` is unchanged),
+    their Adam moments the rows of two more, and an epoch of all K runs is one `ivae_elbo_adam_steps` call whose
+    launches cover every model (grid dimension = model).  Every run keeps its own FusedAdam -- state_dict layout of
+    torch.optim.Adam, the learning rate its own ReduceLROnPlateau sets -- over views of those rows."""
+
+    def __init__(self, models, lr):
+        self.models = models
+        self.shape = models[0]._shape
+        P = models[0]._flat_params().numel()
+        dev = models[0]._flat_params().device
+        self.params = torch.empty(len(models), P, dtype=torch.float32, device=dev)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.steps_taken = 0
+        self.ws = ops.Workspace()
+        self.optimizers = []
+        for i, model in enumerate(models):
+            with torch.no_grad():
+                self.params[i].copy_(model._flat_params())
+                off = 0
+                for p in model.parameters():          # re-home the model's arena in row i
+                    n = p.numel()
+                    p.data = self.params[i, off:off + n].view(p.shape)
+                    off += n
+            model._arena = self.params[i]
+            opt = FusedAdam(model.parameters(), lr=lr)
+            off = 0
+            for p in model.parameters():
+                n = p.numel()
+                opt.state[p] = {'step': torch.tensor(0.), 'exp_avg': self.m[i, off:off + n].view(p.shape),
+                                'exp_avg_sq': self.v[i, off:off + n].view(p.shape)}
+                off += n
+            self.optimizers.append(opt)
+
+    def epoch(self, xs, us, a, b, c, d, N, eps=None, z_out=None):
+        """xs (n_steps, K, B, data_dim) [us (n_steps, K, B, aux_dim)]: zero_grad -> elbo -> backward -> step
+        (runners/ivae.py:75-91) for every step and every run.  -> losses (n_steps, K), z (n_steps, K, B, latent_dim)."""
+        K = len(self.models)
+        if eps is None:
+            eps = torch.randn(xs.shape[0], K, xs.shape[2], self.shape.latent_dim, dtype=torch.float32, device=xs.device)
+        coef = ops.make_coef(a, b, c, d, N, self.models[0]._decoder_var_f, True, xs.shape[2])
+        lrs = [opt.param_groups[0]['lr'] for opt in self.optimizers]
+        g0 = self.optimizers[0].param_groups[0]
+        loss, z = ops.elbo_adam_steps(self.shape, coef, self.params, self.m, self.v, xs, us, eps, self.ws, self.steps_taken,
+                                      lrs, g0['betas'][0], g0['betas'][1], g0['eps'], n_models=K, z_out=z_out)
+        self.steps_taken += xs.shape[0]
+        for opt in self.optimizers:
+            for st in opt.state.values():
+                st['step'] = torch.tensor(float(self.steps_taken))
+        return loss, z
+
+
 def runner(args, config, *, replay=None, trace=None):
     """runners/ivae.py:13-128.  `args`: data_path, seed, n_sims.  `config`: the yaml keys of configs/*.yaml plus
     `device`.  Returns (perfs, loss_hists, perf_hists).
+
+    The reference trains its `n_sims` seeds one after the other; here they are independent models of one packed set and
+    advance together, an epoch of ALL seeds per library call (a 256-CU GPU is idle with one batch-64 model).  Each seed
+    still has its own shuffles, noise, scheduler and learning rate, and the returned lists are in seed order.
 
     Test hooks (tests/test_gpu_runner_trace.py replays runs recorded from the reference's runner draw for draw):
     `replay` supplies the random draws instead of the device generators -- `replay.order(seed, epoch)` the epoch's row
     order (N // B * B indices), `replay.eps(seed, epoch)` the (N // B, B, d_latent) noise of its steps,
     `replay.eval_eps(seed)` the (N, d_latent) noise of the final full-data sample; `trace` (a dict) receives the
-    per-step losses, and per epoch the loss weights and the learning rate after the scheduler's step."""
+    per-step losses, and per epoch the loss weights and the learning rates after the schedulers' steps."""
     st = time.time()
     device = torch.device(config.device)
     print('Executing script on: {}\n'.format(device))
@@ -78,61 +136,69 @@ def runner(args, config, *, replay=None, trace=None):
     d_data, d_latent, d_aux = dset.get_dims()
     X, U, S = dset.x.to(device), dset.u.to(device), dset.s.to(device)
     N, B = len(dset), config.batch_size
+    nb = N // B                               # DataLoader(shuffle=True, drop_last=True), runners/ivae.py:25
     gen = torch.Generator(device=device)
     gen.manual_seed(int(torch.initial_seed()) % (2 ** 63))
 
-    perfs, loss_hists, perf_hists = [], [], []
-    for seed in range(args.seed, args.seed + args.n_sims):
+    seeds = list(range(args.seed, args.seed + args.n_sims))
+    K = len(seeds)
+    models = []
+    for _ in seeds:
         if config.ica:
-            model = cleanIVAE(data_dim=d_data, latent_dim=d_latent, aux_dim=d_aux, hidden_dim=config.hidden_dim,
-                              n_layers=config.n_layers, activation=config.activation, slope=.1).to(device)
+            models.append(cleanIVAE(data_dim=d_data, latent_dim=d_latent, aux_dim=d_aux, hidden_dim=config.hidden_dim,
+                                    n_layers=config.n_layers, activation=config.activation, slope=.1).to(device))
         else:
-            model = cleanVAE(data_dim=d_data, latent_dim=d_latent, hidden_dim=config.hidden_dim,
-                             n_layers=config.n_layers, activation=config.activation, slope=.1).to(device)
-        optimizer = FusedAdam(model.parameters(), lr=config.lr)
-        scheduler = _ReduceLROnPlateau(optimizer, factor=0.1, patience=0)
+            models.append(cleanVAE(data_dim=d_data, latent_dim=d_latent, hidden_dim=config.hidden_dim,
+                                   n_layers=config.n_layers, activation=config.activation, slope=.1).to(device))
+    pack = _SeedPack(models, config.lr)
+    schedulers = [_ReduceLROnPlateau(opt, factor=0.1, patience=0) for opt in pack.optimizers]
+    loss_hists, perf_hists = [[] for _ in seeds], [[] for _ in seeds]
+    tag = (lambda i: '') if K == 1 else (lambda i: '[seed {}] '.format(seeds[i]))
 
-        loss_hist, perf_hist = [], []
-        for epoch in range(1, config.epochs + 1):
+    for epoch in range(1, config.epochs + 1):
+        for model in models:
             model.train()
-            a, b, c, d = config.a, config.b, config.c, config.d
-            if config.anneal:                                     # runners/ivae.py:51-60
-                c = 0
-                if epoch > config.epochs / 1.6:
-                    a, b, c, d = 2 * config.a, 1, 1, 1
-            # one gather per epoch (DataLoader(shuffle=True, drop_last=True), runners/ivae.py:25); batches are views
-            nb = N // B
-            if replay is None:
-                perm, eps = torch.randperm(N, device=device, generator=gen)[:nb * B], None
-            else:
-                perm, eps = replay.order(seed, epoch).to(device), replay.eps(seed, epoch).to(device)
-            Xe, Ue, Se = X[perm].view(nb, B, -1), U[perm].view(nb, B, -1), S[perm].view(nb, B, -1)
-            Ze = torch.empty(nb, B, d_latent, device=device)
-            # zero_grad -> elbo -> backward -> step (runners/ivae.py:75-91) of the whole epoch enqueued by one call
-            losses, _ = model.direct_steps(optimizer, Xe, Ue if config.ica else None, a, b, c, d, N, True, eps=eps,
-                                           z_out=Ze)
-            cc = ops.corr_batched(Se, Ze)       # the per-step batch scores (runners/ivae.py:86), one launch per epoch
-            train_loss = float(losses.sum().item()) / nb      # the epoch's one sync
-            train_perf = float(np.mean(_assignment_scores(cc.abs().cpu().numpy())))
-            perf_hist.append(train_perf)
-            loss_hist.append(train_loss)
-            print('==> Epoch {}/{}:\ttrain loss: {:.6f}\ttrain perf: {:.6f}'.format(epoch, config.epochs, train_loss,
-                                                                                    train_perf))
+        a, b, c, d = config.a, config.b, config.c, config.d
+        if config.anneal:                                     # runners/ivae.py:51-60
+            c = 0
+            if epoch > config.epochs / 1.6:
+                a, b, c, d = 2 * config.a, 1, 1, 1
+        # one gather per epoch and seed; batches are views
+        if replay is None:
+            perm = torch.stack([torch.randperm(N, device=device, generator=gen)[:nb * B] for _ in seeds], 1)
+            eps = None
+        else:
+            perm = torch.stack([replay.order(sd, epoch).to(device) for sd in seeds], 1)
+            eps = torch.stack([replay.eps(sd, epoch).to(device) for sd in seeds], 1).contiguous()
+        perm = perm.view(nb, B, K).transpose(1, 2).contiguous()                      # (nb, K, B)
+        Xe, Se = X[perm], S[perm]                                                     # (nb, K, B, .)
+        Ue = U[perm] if config.ica else None
+        Ze = torch.empty(nb, K, B, d_latent, device=device)
+        losses, _ = pack.epoch(Xe, Ue, a, b, c, d, N, eps=eps, z_out=Ze)              # (nb, K)
+        # the per-step batch scores (runners/ivae.py:86) of all seeds, one launch per epoch
+        cc = ops.corr_batched(Se.reshape(nb * K, B, d_latent), Ze.view(nb * K, B, d_latent))
+        train_loss = (losses.sum(0) / nb).cpu().numpy()                               # the epoch's one sync
+        scores = np.array(_assignment_scores(cc.abs().cpu().numpy())).reshape(nb, K).mean(0)
+        for i in range(K):
+            loss_hists[i].append(float(train_loss[i]))
+            perf_hists[i].append(float(scores[i]))
+            print('{}==> Epoch {}/{}:\ttrain loss: {:.6f}\ttrain perf: {:.6f}'.format(tag(i), epoch, config.epochs,
+                                                                                       train_loss[i], scores[i]))
             if not config.no_scheduler:
-                scheduler.step(train_loss)
-            if trace is not None:
-                trace.setdefault('step_loss', []).append(losses.cpu())
-                trace.setdefault('coef', []).append((a, b, c, d))
-                trace.setdefault('lr', []).append(optimizer.param_groups[0]['lr'])
-        print('\ntotal runtime: {}'.format(time.time() - st))
+                schedulers[i].step(float(train_loss[i]))
+        if trace is not None:
+            trace.setdefault('step_loss', []).append(losses.cpu())
+            trace.setdefault('coef', []).append((a, b, c, d))
+            trace.setdefault('lr', []).append([opt.param_groups[0]['lr'] for opt in pack.optimizers])
+    print('\ntotal runtime: {}'.format(time.time() - st))
 
-        # full-dataset score on a SAMPLE of q(z|x,u), as the reference does (runners/ivae.py:118-123)
-        with torch.no_grad():
-            ev = None if replay is None else replay.eval_eps(seed).to(device)
+    # full-dataset score on a SAMPLE of q(z|x,u), as the reference does (runners/ivae.py:118-123)
+    perfs = []
+    with torch.no_grad():
+        for sd, model in zip(seeds, models):
+            ev = None if replay is None else replay.eval_eps(sd).to(device)
             s = model(X, U, eps=ev)[3] if config.ica else model(X, eps=ev)[3]
-        perfs.append(mcc(S, s))
-        loss_hists.append(loss_hist)
-        perf_hists.append(perf_hist)
+            perfs.append(mcc(S, s))
     return perfs, loss_hists, perf_hists
 
 
