@@ -73,6 +73,7 @@ class DataParallelELBO:
         self.stage = stage_on_cpu
         self.rank, self.world = _world(group)
         self.ws = backend.Workspace()
+        self._gl = None          # [gradient | loss]: written by the kernels, all-reduced as one message
 
     # -- collectives -----------------------------------------------------------------
     def _all_reduce(self, t):
@@ -111,28 +112,30 @@ class DataParallelELBO:
             raise ValueError("rank {} expects rows [{}, {}) of the global batch, got {} rows".format(
                 self.rank, lo, hi, x.shape[0]))
         coef = be.make_coef(a, b, c, d, N, self.decoder_var, pairwise, global_batch)
+        if self._gl is None or self._gl.numel() != params.numel() + 1 or self._gl.device != params.device:
+            self._gl = torch.empty(params.numel() + 1, dtype=torch.float32, device=params.device)
         if not pairwise:
-            loss, z, grads = be.elbo_fwd_bwd(sh, coef, params, x, u, eps, self.ws)
+            loss, z, grads = be.elbo_fwd_bwd(sh, coef, params, x, u, eps, self.ws, gl_out=self._gl)
         else:
             Bl, dl = hi - lo, sh.latent_dim
             z = be.forward(sh, coef, params, x, u, eps, self.ws)
             g_all = self._all_gather_rows(self.ws.view('g', Bl, dl), global_batch)
             v_all = self._all_gather_rows(self.ws.view('v', Bl, dl), global_batch)
-            pw = be.pairwise(coef, z, g_all.contiguous(), v_all.contiguous())
-            cg, cv = self._all_reduce(pw['cg']), self._all_reduce(pw['cv'])
-            for name in ('lq', 'lqi', 'lse_s'):
-                self.ws.view(name, Bl).copy_(pw[name])
-            self.ws.view('lse_k', Bl, dl).copy_(pw['lse_k'])
-            self.ws.view('rz', Bl, dl).copy_(pw['rz'])
+            # the row-side results land in the workspace rows ivae_backward reads; only the column sums travel
+            into = {k: self.ws.view(k, Bl) for k in ('lq', 'lqi', 'lse_s')}
+            into.update({k: self.ws.view(k, Bl, dl) for k in ('lse_k', 'rz')})
+            pw = be.pairwise(coef, z, g_all.contiguous(), v_all.contiguous(), out=into)
+            if self.world > 1:
+                cgv = torch.stack([pw['cg'], pw['cv']])
+                self._all_reduce(cgv)                       # both column terms in one collective
+                cg, cv = cgv[0], cgv[1]
+            else:
+                cg, cv = pw['cg'], pw['cv']
             self.ws.view('cg', Bl, dl).copy_(cg[lo:hi])
             self.ws.view('cv', Bl, dl).copy_(cv[lo:hi])
-            loss, grads = be.backward(sh, coef, params, x, u, eps, self.ws)
-        if self.world > 1:
-            # ONE collective per step: the loss rides behind the gradient (the exchange is latency-bound, 80-190 KB)
-            flat = torch.cat([grads.reshape(-1), loss.reshape(-1)])
-            self._all_reduce(flat)
-            grads = flat[:grads.numel()].view_as(grads)
-            loss = flat[grads.numel():].view_as(loss)
+            loss, grads = be.backward(sh, coef, params, x, u, eps, self.ws, gl_out=self._gl)
+        # ONE collective per step: the loss rides behind the gradient (the exchange is latency-bound, 80-190 KB)
+        self._all_reduce(self._gl)
         return loss, z, grads
 
 

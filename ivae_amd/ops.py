@@ -111,9 +111,22 @@ class Workspace:
         return t.view(batch, width) if width else t
 
 
-def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, z_out=None):
+def _grad_loss_buffers(params, n_models, gl_out):
+    """(grads, loss) as views of one flat [grads | loss] buffer (data-parallel callers all-reduce it as ONE message),
+    or freshly allocated."""
+    dev = params.device
+    if gl_out is None:
+        return torch.empty_like(params), torch.empty(n_models, dtype=torch.float32, device=dev)
+    n = params.numel()
+    if gl_out.dtype != torch.float32 or gl_out.device != dev or not gl_out.is_contiguous() or gl_out.numel() != n + n_models:
+        raise ValueError("gl_out must be a contiguous float32 buffer of params.numel() + n_models elements")
+    return gl_out[:n].view(params.shape), gl_out[n:]
+
+
+def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, z_out=None, gl_out=None):
     """ivae_elbo_fwd_bwd: -> (loss (n_models,), z, grads flat like params).  z_out: write z there (a contiguous fp32
-    tensor of z's shape, e.g. one row block of an epoch's buffer) instead of allocating."""
+    tensor of z's shape, e.g. one row block of an epoch's buffer) instead of allocating.  gl_out: a flat buffer that
+    receives [grads | loss]; the returned tensors are views of it."""
     x = _f32c(x, "x")
     eps = _f32c(eps, "eps")
     params = _f32c(params, "params")
@@ -133,8 +146,7 @@ def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, z_out=None):
             if (z.dtype != torch.float32 or not z.is_contiguous() or z.device != dev
                     or tuple(z.shape) != tuple(x.shape[:-1]) + (shape.latent_dim,)):
                 raise ValueError("z_out must be a contiguous float32 tensor of z's shape on the inputs' device")
-        loss = torch.empty(n_models, dtype=torch.float32, device=dev)
-        grads = torch.empty_like(params)
+        grads, loss = _grad_loss_buffers(params, n_models, gl_out)
         check(_lib.lib().ivae_elbo_fwd_bwd(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps),
                                            _ptr(z), _ptr(loss), _ptr(grads), _ptr(buf), buf.numel() * 4,
                                            _stream(dev)), "ivae_elbo_fwd_bwd")
@@ -199,15 +211,26 @@ def forward(shape, coef, params, x, u, eps, ws, n_models=1):
     return z
 
 
-def pairwise(coef, z, g_cols, v_cols):
-    """ivae_pairwise on explicit row/column tensors -> dict of outputs (single model)."""
+def pairwise(coef, z, g_cols, v_cols, out=None):
+    """ivae_pairwise on explicit row/column tensors -> dict of outputs (single model).  `out`: tensors to write into
+    instead of allocating, by name (any subset of lq lqi lse_s lse_k rz cg cv; e.g. views of the ELBO workspace, so
+    that ivae_backward finds them in place)."""
     z, g_cols, v_cols = _f32c(z, "z"), _f32c(g_cols, "g"), _f32c(v_cols, "v")
     n_rows, d = z.shape
     n_cols = g_cols.shape[0]
     dev = z.device
     mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-    out = dict(lq=mk(n_rows), lqi=mk(n_rows), lse_s=mk(n_rows), lse_k=mk(n_rows, d), rz=mk(n_rows, d),
-               cg=mk(n_cols, d), cv=mk(n_cols, d))
+    shapes = dict(lq=(n_rows,), lqi=(n_rows,), lse_s=(n_rows,), lse_k=(n_rows, d), rz=(n_rows, d), cg=(n_cols, d),
+                  cv=(n_cols, d))
+    given = out or {}
+    out = {}
+    for k, shp in shapes.items():
+        t = given.get(k)
+        if t is None:
+            t = mk(*shp)
+        elif t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() or tuple(t.shape) != shp:
+            raise ValueError("out['{}'] must be a contiguous float32 tensor of shape {} on the inputs' device".format(k, shp))
+        out[k] = t
     nb = C.c_size_t()
     check(_lib.lib().ivae_pairwise_workspace_bytes(n_rows, n_cols, d, C.byref(nb)), "ivae_pairwise_workspace_bytes")
     with torch.cuda.device(dev):
@@ -219,8 +242,8 @@ def pairwise(coef, z, g_cols, v_cols):
     return out
 
 
-def backward(shape, coef, params, x, u, eps, ws, n_models=1):
-    """ivae_backward after forward (+pairwise results copied into the workspace)."""
+def backward(shape, coef, params, x, u, eps, ws, n_models=1, gl_out=None):
+    """ivae_backward after forward (+pairwise results in the workspace).  gl_out: see elbo_fwd_bwd."""
     x = _f32c(x, "x")
     eps = _f32c(eps, "eps")
     u = _f32c(u, "u") if shape.aux_dim > 0 else None
@@ -229,8 +252,7 @@ def backward(shape, coef, params, x, u, eps, ws, n_models=1):
     dev = x.device
     with torch.cuda.device(dev):
         buf = ws.get(dims, dev, coef.pairwise)
-        loss = torch.empty(n_models, dtype=torch.float32, device=dev)
-        grads = torch.empty_like(params)
+        grads, loss = _grad_loss_buffers(params, n_models, gl_out)
         check(_lib.lib().ivae_backward(C.byref(dims), C.byref(coef), _ptr(params), _ptr(x), _ptr(u), _ptr(eps),
                                        _ptr(loss), _ptr(grads), _ptr(buf), buf.numel() * 4, _stream(dev)),
               "ivae_backward")

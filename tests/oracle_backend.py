@@ -63,12 +63,24 @@ def forward(shape, coef, params, x, u, eps, ws, n_models=1):
     return torch.from_numpy(fw["z"].astype(np.float32))
 
 
-def pairwise(coef, z, g_cols, v_cols):
-    out = np_ref.pairwise_terms(z.numpy(), g_cols.numpy(), v_cols.numpy(), _ocoef(coef), coef.global_batch)
-    return {k: torch.from_numpy(np.ascontiguousarray(v).astype(np.float32)) for k, v in out.items()}
+def pairwise(coef, z, g_cols, v_cols, out=None):
+    res = np_ref.pairwise_terms(z.numpy(), g_cols.numpy(), v_cols.numpy(), _ocoef(coef), coef.global_batch)
+    res = {k: torch.from_numpy(np.ascontiguousarray(v).astype(np.float32)) for k, v in res.items()}
+    for k, t in (out or {}).items():
+        t.copy_(res[k])
+        res[k] = t
+    return res
 
 
-def backward(shape, coef, params, x, u, eps, ws, n_models=1):
+def _into(gl_out, loss, grads):
+    if gl_out is None:
+        return loss, grads
+    gl_out[:grads.numel()].copy_(grads)
+    gl_out[grads.numel():].copy_(loss)
+    return gl_out[grads.numel():], gl_out[:grads.numel()]
+
+
+def backward(shape, coef, params, x, u, eps, ws, n_models=1, gl_out=None):
     spec = _spec(shape, coef)
     fw, oc = ws.fw, _ocoef(coef)
     row = coef.a * fw["lpx"] - coef.b * fw["lqc"] + coef.d * fw["lp"]
@@ -80,17 +92,17 @@ def backward(shape, coef, params, x, u, eps, ws, n_models=1):
     G = np_ref.elbo_backward(_unflat(spec, params), x.numpy(), None if u is None else u.numpy(), fw, spec, oc, np.float64,
                              global_batch=coef.global_batch, pair=pair)
     loss = torch.tensor([-row.sum() / coef.global_batch], dtype=torch.float32)
-    return loss, _flat(spec, G)
+    return _into(gl_out, loss, _flat(spec, G))
 
 
-def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1):
+def elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=1, gl_out=None):
     z = forward(shape, coef, params, x, u, eps, ws)
     if coef.pairwise:
         if coef.global_batch != x.shape[0]:
             raise RuntimeError("pairwise shards need the phase entry points")
         pw = pairwise(coef, z, ws.t["g"], ws.t["v"])
         ws.t.update(pw)
-    loss, grads = backward(shape, coef, params, x, u, eps, ws)
+    loss, grads = backward(shape, coef, params, x, u, eps, ws, gl_out=gl_out)
     return loss, z, grads
 
 

@@ -26,38 +26,57 @@ def _flat(group, names):
     return np.concatenate([group[n].reshape(-1) for n in names])
 
 
-def _worker(rank, world, port, name, out):
+def _worker(rank, world, port, name, out, backend="gloo"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    rccl = backend == "nccl"                 # one device per rank, collectives on device tensors over xGMI
+    if rccl:
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from ivae_amd import ops
         from ivae_amd.dist import DataParallelELBO, row_range
         c = Case(name)
         s = c.spec
         shape = ops.ModelShape(s.data_dim, s.latent_dim, s.aux_dim, s.hidden_dim, s.n_layers, s.activation, s.slope)
-        d = torch.device("cuda:0")
+        d = torch.device("cuda", rank if rccl else 0)
         x, u, eps = c.inputs()
         B = x.shape[0]
         lo, hi = row_range(B, rank, world)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
         co = c.coef(0)
-        dp = DataParallelELBO(shape, s.decoder_var, stage_on_cpu=True)
+        dp = DataParallelELBO(shape, s.decoder_var, stage_on_cpu=not rccl)
         loss, z, grads = dp.fwd_bwd(t(_flat(c.params, s.param_names())), t(x[lo:hi]), t(u[lo:hi]) if s.aux_dim else None,
                                     t(eps[lo:hi]), B, a=co.a, b=co.b, c=co.c, d=co.d, N=co.N, pairwise=co.pairwise)
         torch.cuda.synchronize()
-        out.put((rank, float(loss[0]), z.cpu().numpy(), grads.cpu().numpy()))
+        out.put((rank, float(loss[0]), z.cpu().numpy(), grads.cpu().numpy().copy()))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("name", ["ivae_plain_cfg4s", "cleanivae_lrelu_b70", "cleanvae_btcvae_b200"])
 def test_two_ranks_match_full_batch_fixture(name):
+    _two_ranks(name, "gloo")
+
+
+@pytest.mark.parametrize("name", ["ivae_plain_cfg4s", "cleanivae_lrelu_b70"])
+def test_two_ranks_over_rccl_match_full_batch_fixture(name):
+    """The same exchange with backend "nccl" (= RCCL over xGMI), one GPU per rank: runs wherever two GPUs are visible
+    (the builder's box has one, the driver's node has eight)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL takes one device per rank")
+    _two_ranks(name, "nccl")
+
+
+def _two_ranks(name, backend):
     c = Case(name)
     names = c.spec.param_names()
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, out, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([out.get() for _ in procs], key=lambda t: t[0])

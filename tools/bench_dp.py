@@ -25,9 +25,24 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--pairwise", action="store_true", help="include the BxBxd total-correlation terms (all-gather path)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # start the ranks ourselves (a child process, before this one touches the GPU) and leave with its exit code
+        import socket
+        import subprocess
+        have = torch.cuda.device_count()
+        if args.gpus > have:
+            sys.exit("bench_dp.py: --gpus %d asked for, %d GPU(s) visible" % (args.gpus, have))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                                  str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                  os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench_dp.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
