@@ -908,6 +908,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             STAMPW(3);
             flag_wait(flagV + rt * ST, step_no);
             STAMPW(4);
+
             // reparameterisation z = g + eps * sqrt(v) (nets.py:301-304), rows of this tile: lane = (row, a quarter of the
             // SS columns); all loads first, v_sqrt_f32 (1 ulp)
             {

@@ -279,6 +279,30 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
     ckpt_every = int(max_iter / 5)
     d = model.latent_dim
 
+    def last(key):
+        vals = logger.log_dict[key]
+        return vals[-1] if vals else float('nan')       # (the reference would raise here inside the first epoch)
+
+    def maybe_checkpoint(it):
+        """wrappers.py:78-80: a checkpoint whenever `it` is a multiple of max_iter / 5, holding the state AT that iteration."""
+        if ckpt_folder is not None and ckpt_every > 0 and it % ckpt_every == 0:
+            opt = drv.as_optimizer() if fused else optimizer
+            checkpoint(ckpt_folder, exp_id, it, model, opt, last('elbo'), last('perf'))
+
+    def segments(it, n):
+        """[a, b) pieces of the next n iterations, cut where a checkpoint falls due (so every piece is one library call
+        and the state a checkpoint stores is the state of its iteration)."""
+        cuts, a = [], 0
+        if ckpt_folder is not None and ckpt_every > 0:
+            m = (it // ckpt_every + 1) * ckpt_every
+            while m < it + n:
+                cuts.append(m - it)
+                m += ckpt_every
+        for c in cuts + [n]:
+            if c > a:
+                yield a, c
+            a = c
+
     print("Training..")
     it = 0
     model.train()
@@ -286,34 +310,38 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
         epoch = it // n_batches + 1
         batches = _epoch_batches(N, batch_size, False, device, gen)
         cc = torch.empty(len(batches), d, d, dtype=torch.float64, device=device) if S is not None else None
-        it0 = it
+        n_full = N // batch_size
         if fused:
-            n_full = N // batch_size
-            idx = torch.stack(batches[:n_full]).to(torch.int32)
             drv.group['lr'] = scheduler.optimizer.param_groups[0]['lr']
-            loss, zs = drv.full_batches(X, U, idx)
-            logger.update('elbo', loss.sum(), weight=n_full)
-            if cc is not None and n_full:       # the per-step batch scores (wrappers.py:75), one launch per epoch
-                cc[:n_full] = ops.corr_batched(zs.reshape(n_full, batch_size, d).contiguous(),
-                                               Z[idx.long().view(-1)].view(n_full, batch_size, d))
-            it += n_full
+            if n_full:
+                idx = torch.stack(batches[:n_full]).to(torch.int32)
+                zs = torch.empty(n_full, batch_size, d, device=device)
+                for a0, b0 in segments(it, n_full):
+                    loss, zs[a0:b0] = drv.full_batches(X, U, idx[a0:b0].contiguous())
+                    logger.update('elbo', loss.sum(), weight=b0 - a0)
+                    it += b0 - a0
+                    maybe_checkpoint(it)
+                if cc is not None:              # the per-step batch scores (wrappers.py:75), one launch per epoch
+                    cc[:n_full] = ops.corr_batched(zs, Z[idx.long().view(-1)].view(n_full, batch_size, d))
             for i in range(n_full, len(batches)):
                 l1, z1 = drv.ragged_batch(X[batches[i]], None if U is None else U[batches[i]])
                 logger.update('elbo', l1)
                 if cc is not None:
                     cc[i] = corr_matrix_gpu(z1, Z[batches[i]])
                 it += 1
+                maybe_checkpoint(it)
         else:
-            n_full = N // batch_size
             Ze = torch.empty(n_full, batch_size, d, device=device) if cc is not None else None
             first = 0
             if not anneal and n_full:
-                # constant loss weights: the epoch's full batches go through ONE ivae_elbo_adam_steps call
+                # constant loss weights: the epoch's full batches go through ivae_elbo_adam_steps, one call per piece
                 idx = torch.stack(batches[:n_full])
-                losses, _ = model.direct_steps(optimizer, X[idx], U[idx] if with_u else None, 1., 1., 1., 1., 1., False,
-                                               z_out=Ze)
-                logger.update('elbo', losses.sum(), weight=n_full)
-                it += n_full
+                for a0, b0 in segments(it, n_full):
+                    losses, _ = model.direct_steps(optimizer, X[idx[a0:b0]], U[idx[a0:b0]] if with_u else None, 1., 1., 1.,
+                                                   1., 1., False, z_out=None if Ze is None else Ze[a0:b0])
+                    logger.update('elbo', losses.sum(), weight=b0 - a0)
+                    it += b0 - a0
+                    maybe_checkpoint(it)
                 first = n_full
             for i, bidx in enumerate(batches):
                 if i < first:
@@ -334,18 +362,13 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                 logger.update('elbo', loss)
                 if cc is not None and not full:
                     cc[i] = corr_matrix_gpu(z_est, Z[bidx])
+                maybe_checkpoint(it)
             if Ze is not None and n_full:
                 cc[:n_full] = ops.corr_batched(Ze, Z[torch.stack(batches[:n_full]).view(-1)].view(n_full, batch_size, d))
         if cc is not None:
             for score in _assignment_scores(cc.abs().cpu().numpy()):
                 logger.update('perf', score)
         logger.log()
-        # checkpoints fall on multiples of max_iter/5 (wrappers.py:78-80); written at the end of the epoch that
-        # crosses one, since a whole epoch is one launch chain here
-        if ckpt_folder is not None and ckpt_every > 0 and it // ckpt_every > it0 // ckpt_every:
-            opt = drv.as_optimizer() if fused else optimizer
-            checkpoint(ckpt_folder, exp_id, (it // ckpt_every) * ckpt_every, model, opt, logger.get_last('elbo'),
-                       logger.get_last('perf'))
         scheduler.step(logger.get_last('elbo'))
         if S is not None:
             print('epoch {}/{} \tloss: {}\tperf: {}'.format(epoch, max_epochs, logger.get_last('elbo'),

@@ -63,6 +63,25 @@ def test_ivae_wrapper_fused_epochs_and_checkpoints(tmp_path):
     st = ck['optimizer_state_dict']['state']
     assert len(st) == 24 and set(st[0]) == {'step', 'exp_avg', 'exp_avg_sq'}
     assert st[0]['exp_avg'].shape == model.logl.fc[0].weight.shape
+    assert ck['iteration'] == 123 and int(st[0]['step']) == 123        # the state OF that iteration (files[0] is ..._ckpt_123)
+
+
+@pytest.mark.parametrize("hidden", [50, 20])          # 50: fused epochs; 20: generic kernels
+def test_wrapper_checkpoints_inside_one_epoch_and_tiny_datasets(tmp_path, hidden):
+    """wrappers.py:78-80 checkpoints at every multiple of max_iter / 5, wherever it falls: several inside one epoch here
+    (41 batches per epoch, one checkpoint every 4 iterations), each holding the optimiser state of ITS iteration.  And a
+    dataset smaller than one batch (only the ragged batch exists) trains too."""
+    X, U, S = _cfg2_like(65)
+    _, model, _, logger = runners.IVAE_wrapper(X, U, S, batch_size=64, max_iter=20, seed=3, hidden_dim=hidden, lr=1e-2,
+                                               log_folder=str(tmp_path / 'log'), ckpt_folder=str(tmp_path / 'ckpt') + '/')
+    files = glob.glob(str(tmp_path / 'ckpt') + '/*/*_ckpt_*.pth')
+    its = sorted(int(os.path.basename(f).split('_ckpt_')[1][:-4]) for f in files)
+    assert its[:5] == [4, 8, 12, 16, 20]
+    for f in files:
+        ck = torch.load(f, weights_only=True)
+        assert int(ck['optimizer_state_dict']['state'][0]['step']) == ck['iteration']
+    z, _, _, lg = runners.IVAE_wrapper(X[:40], U[:40], S[:40], batch_size=64, max_iter=3, seed=3, hidden_dim=hidden, lr=1e-2)
+    assert z.shape == (40, 10) and len(lg.log_dict['elbo']) == 3 and all(np.isfinite(lg.log_dict['elbo']))
 
 
 def test_wrappers_generic_path_matches_fused_path_statistically():
