@@ -164,6 +164,14 @@ __device__ __forceinline__ float flog(float x) { return 0.6931471805599453f * __
 // e^x on the hardware exp2 unit (v_exp_f32, 1 ulp in exp2; the argument's rounding adds |x| * 6e-8 relative)
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
 
+// Workgroup barrier number n of the step (diagnostic builds: -DFT_SKIP_BAR=n leaves that one out -- timing experiment
+// only, the results are wrong -- to see what each barrier costs).
+#ifdef FT_SKIP_BAR
+#define BAR(n) do { if ((n) != FT_SKIP_BAR) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(n); } while (0)
+#else
+#define BAR(n) do { lds_barrier(); STAMP(n); } while (0)
+#endif
+
 #define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
 // LDS offsets are far below 2^23: full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
@@ -870,7 +878,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         // row index of the next step's batch (the last step re-reads its own: unconditional, so that the wait-count
         // pass never sees a load that is pending on one path only and answers with a vmcnt(0) mid-phase)
         const int next_row = min(max(idxp[(size_t)min(s + 1, A.n_steps - 1) * FT_B + (tid >> 3)], 0), last_row);
-        lds_barrier(); STAMP(1);
+        BAR(1);
 
         // ---- forward stage, wave-local chains (no workgroup barrier inside).  Row tile rt = w & 3 is owned by the
         // two waves of one SIMD: wave rt runs the g chain and then the decoder, wave rt + 4 the logv chain and then the
@@ -1012,7 +1020,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 lsum += A.d * lp - A.b * lqc;
             }
         }
-        lds_barrier(); STAMP(8);
+        BAR(8);
 #ifdef FT_ABL_NOBWD            // timing experiment only
         if (A.n_steps < 0) {
 #endif
@@ -1020,12 +1028,12 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         // ---- BF3: d2f -> T1; decoder-head gradient -> T0 + STG_F2 (waves 0-3)
         dgrad_hidden<C, SS, DD, KS_H, H>(sO, SS, arena + C::off_of(L_F2), T4, T1, slope, w);
         if (w < 4) wgrad_tile<C, DD, KS_H, H>(sO, SS, T4, ST, T0 + C::STG_F2, 0, w);
-        lds_barrier(); STAMP(9);
+        BAR(9);
         // ---- BF2: d1f -> T4; layer-2 gradient -> T0; Adam(F2)
         stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_F1), T2, T4, slope, w); },
                 LAMBDA { wgrad_pair<C, H, KS_H, H, true>(T1, ST, T2, ST, T0, w);     // guarded: the tile's tail holds the F2 stage
                          ADAM(L_F2, T0 + C::STG_F2); });
-        lds_barrier(); STAMP(10);
+        BAR(10);
         // ---- BF1: dLoss/dz -> sD (waves 0-3); layer-1 gradient -> stF0 (waves 4-7); Adam(F1)
         stagger(w, LAMBDA {
             if (w < 4) {
@@ -1037,7 +1045,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 wgrad_tile<C, H, KS_F0, DL>(T4, ST, sZ, SS, stF0, w - 4, 0);
             }
         }, LAMBDA { ADAM(L_F1, T0); });
-        lds_barrier(); STAMP(11);
+        BAR(11);
         // ---- E: head deltas in place (SURVEY §8 a-bwd): sG <- dg, sV <- dlogv, sL <- dlogl; Adam(F0);
         //         h2g -> T2, h1g -> T4 (operands of the encoder's weight gradients)
         for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
@@ -1064,7 +1072,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0) red[w] = v;
         }
-        lds_barrier(); STAMP(12);
+        BAR(12);
 
         // ---- G3: d2g -> T0; head gradient -> sZ (z is dead); loss out
         if (tid == 0) {
@@ -1073,30 +1081,30 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         }
         dgrad_hidden<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), T2, T0, slope, w);
         if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
-        lds_barrier(); STAMP(13);
+        BAR(13);
         // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
         stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), T4, T2, slope, w); },
                 LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_G2, sZ); });
-        lds_barrier(); STAMP(14);
+        BAR(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
         WGRAD_ADAM(H, KS_E0, C::KIN, T2, ST, T3, ST, T0, L_G1, T1);
         if (w >= 4) restore_rows<C>(s2, T4, rt);
-        lds_barrier(); STAMP(15);
+        BAR(15);
 
         // ---- V3: d2v -> T1; head gradient -> sZ; Adam(G0); h1v -> T2
         stagger(w, LAMBDA {
                     dgrad_hidden<C, SS, DL, KS_H, H>(sV, SS, arena + C::off_of(L_V2), T4, T1, slope, w);
                     if (w < 4) wgrad_tile<C, DL, KS_H, H>(sV, SS, T4, ST, sZ, 0, w);
                 }, LAMBDA { ADAM(L_G0, T0); if (w >= 4) restore_rows<C>(s1, T2, rt); });
-        lds_barrier(); STAMP(16);
+        BAR(16);
         // ---- V2: d1v -> T4; layer-2 gradient -> T0; Adam(V2)
         stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), T2, T4, slope, w); },
                 LAMBDA { wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w); ADAM(L_V2, sZ); });
-        lds_barrier(); STAMP(17);
+        BAR(17);
         // ---- V1: layer-1 gradient -> T1; Adam(V1); h2l -> T2
         WGRAD_ADAM(H, KS_E0, C::KIN, T4, ST, T3, ST, T1, L_V1, T0);
         if constexpr (C::HAS_U) { if (w >= 4) restore_rows<C>(s3, T2, rt); }
-        lds_barrier(); STAMP(18);
+        BAR(18);
 
         if constexpr (C::HAS_U) {
             // ---- L3: d2l -> T0; head gradient -> sZ; Adam(V0); h1l -> T4
@@ -1104,14 +1112,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                         dgrad_hidden<C, SS, DL, KS_H, H>(sL, SS, arena + C::off_of(L_L2), T2, T0, slope, w);
                         if (w < 4) wgrad_tile<C, DL, KS_H, H>(sL, SS, T2, ST, sZ, 0, w);
                     }, LAMBDA { ADAM(L_V0, T1); if (w < 4) restore_rows<C>(s3, T4, rt); });
-            lds_barrier(); STAMP(19);
+            BAR(19);
             // ---- L2: d1l -> T2; layer-2 gradient -> T1; Adam(L2)
             stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), T4, T2, slope, w); },
                     LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_L2, sZ); });
-            lds_barrier(); STAMP(20);
+            BAR(20);
             // ---- L1: layer-1 gradient -> T0; Adam(L1)
             WGRAD_ADAM(H, KS_L0, M, T2, ST, T3 + C::UOFF, ST, T0, L_L1, T1);
-            lds_barrier(); STAMP(21);
+            BAR(21);
         }
 #ifdef FT_ABL_NOBWD
         }

@@ -11,6 +11,7 @@ for steps in 125 20; do
     rm -rf $d
     timeout -s KILL 120 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --steps $((steps * 2)) --warmup $steps --steps-per-launch $steps --no-cpu-baseline --no-other-configs > $d.log 2>&1
     python3 $R/tools/pmc_summary.py $(find $d -name '*.db' | head -1) k_train_steps > $R/gpurun_out/pmc/${ctr}_${steps}.txt
+    rm -rf $d
     cat $R/gpurun_out/pmc/${ctr}_${steps}.txt
   done
 done

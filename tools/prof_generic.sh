@@ -8,6 +8,7 @@ for c in cfg0 cfg2 cfg3; do
   rm -rf $R/gpurun_out/prof_$c
   timeout -k 10 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$c -o run -- python3 $R/tools/time_generic.py $c > $R/gpurun_out/prof_$c.log 2>&1
   python3 $R/tools/kernel_stats.py $(find $R/gpurun_out/prof_$c -name '*.db' | head -1) $R/gpurun_out/ks_$c.csv
+  rm -rf $R/gpurun_out/prof_$c
   tail -1 $R/gpurun_out/prof_$c.log
   head -12 $R/gpurun_out/ks_$c.csv
 done
