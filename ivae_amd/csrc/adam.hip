@@ -12,11 +12,9 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, float* __re
                                               const float* __restrict__ g, int64_t n, float w1, float b2, float w2,
                                               float neg_step, float bc2_sqrt, float eps) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i];
-        const float mi = m[i] + w1 * (gi - m[i]);
-        const float vi = v[i] * b2 + (w2 * gi) * gi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] + (neg_step * mi) / denom;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_update(pi, mi, vi, g[i], w1, b2, w2, neg_step, bc2_sqrt, eps);
+        p[i] = pi;
         m[i] = mi;
         v[i] = vi;
     }
@@ -37,7 +35,6 @@ hipError_t launch_adam(float* p, float* m, float* v, const float* g, int64_t n, 
 
 // Packed models with their own learning rates (every run of a packed seed sweep has its own ReduceLROnPlateau,
 // runners/ivae.py:39,113-114): blockIdx.y = model, its step size travels in the kernel arguments.
-#define ADAM_MODELS_PER_LAUNCH 256
 struct AdamModelSteps { float neg_step[ADAM_MODELS_PER_LAUNCH]; };
 
 __global__ __launch_bounds__(256) void k_adam_models(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
@@ -47,11 +44,9 @@ __global__ __launch_bounds__(256) void k_adam_models(float* __restrict__ p, floa
     const float neg_step = S.neg_step[blockIdx.y];
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_per_model; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = base + j;
-        const float gi = g[i];
-        const float mi = m[i] + w1 * (gi - m[i]);
-        const float vi = v[i] * b2 + (w2 * gi) * gi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] + (neg_step * mi) / denom;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_update(pi, mi, vi, g[i], w1, b2, w2, neg_step, bc2_sqrt, eps);
+        p[i] = pi;
         m[i] = mi;
         v[i] = vi;
     }

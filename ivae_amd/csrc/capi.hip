@@ -104,10 +104,12 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_backward");
 }
 
-int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
-                      const float* eps, float* z_out, float* loss_out, float* grads, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+// fuse != null: the slab reduction also applies the Adam update (*fused says whether it did)
+static int fwd_bwd_impl(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
+                        const float* eps, float* z_out, float* loss_out, float* grads, void* workspace,
+                        size_t workspace_bytes, void* stream, const AdamFuse* fuse, bool* fused) {
     Layout L;
+    if (fused) *fused = false;
     if (!coef) return IVAE_E_NULLPTR;
     int rc = ivae_make_layout(dims, coef->pairwise != 0, &L);
     if (rc) return rc;
@@ -125,8 +127,14 @@ int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* p
                             L.n_models, (size_t)L.ws.per_model, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "ivae_elbo_fwd_bwd");
     }
-    e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, true, (hipStream_t)stream);
+    e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, true, (hipStream_t)stream, fuse, fused);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_elbo_fwd_bwd");
+}
+
+int ivae_elbo_fwd_bwd(const IvaeDims* dims, const IvaeCoef* coef, const float* params, const float* x, const float* u,
+                      const float* eps, float* z_out, float* loss_out, float* grads, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    return fwd_bwd_impl(dims, coef, params, x, u, eps, z_out, loss_out, grads, workspace, workspace_bytes, stream, nullptr, nullptr);
 }
 
 int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float* grads, int64_t n, double lr,
@@ -150,12 +158,23 @@ int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, float* para
     int64_t P = 0;
     if ((rc = ivae_param_count(dims, &P))) return rc;
     const size_t rows = (size_t)dims->n_models * dims->batch;
+    AdamFuse F;
+    F.p = params; F.m = exp_avg; F.v = exp_avg_sq;
+    F.w1 = (float)(1.0 - beta1); F.b2 = (float)beta2; F.w2 = (float)(1.0 - beta2); F.eps = (float)adam_eps;
+    const bool can_fuse = dims->n_models <= ADAM_MODELS_PER_LAUNCH;
     for (int s = 0; s < n_steps; ++s) {
-        rc = ivae_elbo_fwd_bwd(dims, coef, params, x_steps + s * rows * dims->data_dim,
-                               u_steps ? u_steps + s * rows * dims->aux_dim : nullptr, eps_steps + s * rows * dims->latent_dim,
-                               z_steps + s * rows * dims->latent_dim, loss_out + (size_t)s * dims->n_models, grads, workspace,
-                               workspace_bytes, stream);
+        if (can_fuse) {          // same constants as launch_adam / launch_adam_models form for this step
+            const double bc1 = 1.0 - pow(beta1, (double)(step0 + s + 1));
+            F.bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)(step0 + s + 1)));
+            for (int i = 0; i < dims->n_models; ++i) F.neg_step[i] = (float)(-(model_lr ? model_lr[i] : lr) / bc1);
+        }
+        bool fused = false;
+        rc = fwd_bwd_impl(dims, coef, params, x_steps + s * rows * dims->data_dim,
+                          u_steps ? u_steps + s * rows * dims->aux_dim : nullptr, eps_steps + s * rows * dims->latent_dim,
+                          z_steps + s * rows * dims->latent_dim, loss_out + (size_t)s * dims->n_models, grads, workspace,
+                          workspace_bytes, stream, can_fuse ? &F : nullptr, &fused);
         if (rc) return rc;
+        if (fused) continue;     // the gradient reduction applied the update
         if (model_lr) {
             hipError_t e = launch_adam_models(params, exp_avg, exp_avg_sq, grads, P, dims->n_models, model_lr, beta1, beta2,
                                               adam_eps, step0 + s + 1, (hipStream_t)stream);

@@ -805,8 +805,9 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
 // order, so the result does not depend on scheduling.
 #define RED_P 256
 #define RED_W 16          // waves of a k_reduce block: wave g sums the slabs g, g + 16, ...
+template <bool ADAM>
 __global__ __launch_bounds__(64 * RED_W) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
-                                                       float* __restrict__ grads, float* __restrict__ loss_out) {
+                                                       float* __restrict__ grads, float* __restrict__ loss_out, AdamFuse F) {
     const int model = blockIdx.y;
     const float* wsm = ws + (size_t)model * L.ws.per_model;
     const int nblk_p = L.n_wtiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;   // one tile: the kernels wrote grads directly
@@ -838,7 +839,17 @@ __global__ __launch_bounds__(64 * RED_W) void k_reduce(Layout L, IvaeCoef C, con
             const int p0 = (int)blockIdx.x * RED_P + 4 * l;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (p0 + e < L.n_params) grads[(size_t)model * L.n_params + p0 + e] = r[e];
+                if (p0 + e < L.n_params) {
+                    const size_t i = (size_t)model * L.n_params + p0 + e;
+                    grads[i] = r[e];
+                    if (ADAM) {          // the optimiser step of this element, by the thread that just formed its gradient
+                        float pi = F.p[i], mi = F.m[i], vi = F.v[i];
+                        adam_update(pi, mi, vi, r[e], F.w1, F.b2, F.w2, F.neg_step[model], F.bc2_sqrt, F.eps);
+                        F.p[i] = pi;
+                        F.m[i] = mi;
+                        F.v[i] = vi;
+                    }
+                }
         }
         return;
     }
@@ -910,7 +921,9 @@ hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* param
 }
 
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                           const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st) {
+                           const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st,
+                           const AdamFuse* fuse, bool* fused) {
+    if (fused) *fused = false;
     hipError_t e;
     if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     const int nblk_p = L.n_wtiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
@@ -918,6 +931,11 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
     if ((e = launch_phase(L, C, 4, params, x, u, eps, nblk_p == 0 ? loss_out : nullptr, ws, grads, st)) != hipSuccess) return e;
     if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     if (nblk_p == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_reduce, dim3(nblk_p + 1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out);
+    if (fuse && L.n_models <= ADAM_MODELS_PER_LAUNCH) {
+        hipLaunchKernelGGL(k_reduce<true>, dim3(nblk_p + 1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out, *fuse);
+        if (fused) *fused = true;
+    } else {
+        hipLaunchKernelGGL(k_reduce<false>, dim3(nblk_p + 1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out, AdamFuse{});
+    }
     return hipGetLastError();
 }

@@ -5,8 +5,31 @@
 
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
                           const float* eps, float* z_out, float* ws, float* grads_for_dec_bwd, hipStream_t st);
+// Adam update fused into the slab reduction of launch_backward (ivae_elbo_adam_steps): the thread that forms a gradient
+// element applies it, so a training step needs no separate optimiser launch.  Step sizes per model (at most
+// ADAM_MODELS_PER_LAUNCH models; the caller falls back to the separate launch beyond that).
+#define ADAM_MODELS_PER_LAUNCH 256
+struct AdamFuse {
+    float* p; float* m; float* v;
+    float w1, b2, w2, bc2_sqrt, eps;
+    float neg_step[ADAM_MODELS_PER_LAUNCH];
+};
+// The update of torch.optim.Adam's single-tensor path (optim/adam.py:457-547), shared by every kernel that applies it.
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float g, float w1, float b2, float w2,
+                                            float neg_step, float bc2_sqrt, float eps) {
+    // contractions written out: the same bits whichever kernel this is inlined into
+    const float mi = __fmaf_rn(w1, __fsub_rn(g, m), m);
+    const float vi = __fmaf_rn(__fmul_rn(w2, g), g, __fmul_rn(v, b2));
+    const float denom = __fadd_rn(__fdiv_rn(sqrtf(vi), bc2_sqrt), eps);
+    p = __fadd_rn(p, __fdiv_rn(__fmul_rn(neg_step, mi), denom));
+    m = mi;
+    v = vi;
+}
+// fuse != null: also apply Adam (returns hipErrorNotSupported-free: *fused tells the caller whether it happened -- a model
+// whose gradient needs no slab reduction has no k_reduce launch to ride on).
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                           const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st);
+                           const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st,
+                           const AdamFuse* fuse = nullptr, bool* fused = nullptr);
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
                            const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
                            float* cg, float* cv, float* ws, int n_models, size_t mstride, hipStream_t st);
