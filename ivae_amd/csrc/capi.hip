@@ -118,7 +118,8 @@ static int fwd_bwd_impl(const IvaeDims* dims, const IvaeCoef* coef, const float*
     if (workspace_bytes < (size_t)L.ws.per_model * L.n_models * sizeof(float)) return IVAE_E_WORKSPACE;
     if (coef->pairwise && coef->global_batch != dims->batch) return IVAE_E_BADDIMS;   // DP callers run the phases themselves
     // the decoder's backward rides in the decoder's forward launch (it needs nothing from other rows)
-    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, grads, (hipStream_t)stream);
+    int done = 0;               // plain ELBO: the row-chain kernel (where it serves the layout) also runs the encoder backward
+    hipError_t e = launch_forward(L, *coef, params, x, u, eps, z_out, (float*)workspace, grads, (hipStream_t)stream, true, &done);
     if (e != hipSuccess) return hip_fail(e, "ivae_elbo_fwd_bwd");
     if (coef->pairwise) {       // all packed models in one launch sequence (their arrays repeat with the workspace stride)
         float* w = (float*)workspace;
@@ -127,7 +128,8 @@ static int fwd_bwd_impl(const IvaeDims* dims, const IvaeCoef* coef, const float*
                             L.n_models, (size_t)L.ws.per_model, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "ivae_elbo_fwd_bwd");
     }
-    e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, true, (hipStream_t)stream, fuse, fused);
+    e = launch_backward(L, *coef, params, x, u, eps, loss_out, grads, (float*)workspace, true, (hipStream_t)stream, fuse, fused,
+                        (done & 4) != 0);
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_elbo_fwd_bwd");
 }
 

@@ -29,10 +29,8 @@
 #include "kernels.h"
 
 #define NR 256            // threads of a loss reduction
-#define KCH 64            // contraction extent of a staged chunk
-#define LDC 68            // chunk row stride (4 * odd)
-// Geometry of a workgroup of NW waves (4, 8 or 16): NT threads, chunks of NCH = 16 NW rows (output columns) x KCH
-#define GEOM(NW) constexpr int NT = 64 * (NW), NCH = 16 * (NW), CHUNK = NCH * LDC; (void)NT; (void)NCH; (void)CHUNK
+// Geometry of a workgroup of NW waves (4, 8 or 16): NT threads, NCH = 16 NW output columns per pass (one tile per wave)
+#define GEOM(NW) constexpr int NT = 64 * (NW), NCH = 16 * (NW); (void)NT; (void)NCH
 #define LOG2PI 1.8378770664093453f
 
 // Diagnostic build only (-DMF_PROF): s_memtime stamps of workgroup 0 / thread 0 go to a buffer of their own; no
@@ -52,8 +50,28 @@ __device__ unsigned long long* g_mf_prof = nullptr;
 extern "C" int ivae_debug_set_prof_mf(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mf_prof), &buf, sizeof(buf));
 }
+// k_wgrad: stamps of the job blockIdx = (0, 0, MF_PROF_Z), slots 1500 + i
+#ifndef MF_PROF_Z
+#define MF_PROF_Z 3
+#endif
+#define WSTAMP(i)                                                                                   \
+    do {                                                                                            \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 64 * MF_PROF_Z && g_mf_prof) {          \
+            unsigned long long t_;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            g_mf_prof[2 * (1500 + (i))] = (i);                                                      \
+            g_mf_prof[2 * (1500 + (i)) + 1] = t_;                                                   \
+        }                                                                                           \
+    } while (0)
+#ifdef MF_PROF_FINE
+#define MSTAMPF(id) MSTAMP(id)
+#else
+#define MSTAMPF(id)
+#endif
 #else
 #define MSTAMP(id)
+#define MSTAMPF(id)
+#define WSTAMP(i)
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -73,194 +91,197 @@ __device__ __forceinline__ void act_both(float p, int act, float slope, float& h
 }
 
 // ------------------------------------------------------------------------------ streamed operand
-// Source of the streamed operand Bm[j][k] (j: output column, k: contraction index) of one product.
+// Source of the register-streamed operand Bm[j][k] (j: output column, k: contraction index) of one product.
 //   SRC_W    forward:  Bm[j][k] = W[j][k] (W is (J, K) row-major at p), Bm[j][K] = bias[j] (at p + d2): the A tiles
-//            carry a constant-1 column at k = K.  k in [hole0, hole0 + hole) is padding (zero) and later k shift
-//            down by `hole` ([x | pad | u | 1] input tiles).
+//            carry a constant-1 column at k = K.  k in [hole0, hole0 + hole) is padding (the A tile is zero there) and
+//            later k shift down by `hole` ([x | pad | u | 1] input tiles).
 //   SRC_WT   dgrad:    Bm[j][k] = W[k][j]   (W is (K, J) row-major at p, row stride ld)
-//   SRC_PRE  wgrad of a hidden layer:  Bm[j][k] = actT[j][k] (hidden activations feature-major at p, row stride ld,
-//            k = batch row < K), Bm[J][k] = 1 (its result row is the bias gradient)
-//   SRC_ROWS wgrad of a first layer:   Bm[j][k] = in[k][j], in = [a | b] row-major blocks (a: J1 columns at p, row
-//            stride ld; b: J - J1 columns at p + d2, row stride ld2), Bm[J][k] = 1
-// Everything outside the stated extents is zero.
-enum { SRC_NONE = 0, SRC_W, SRC_WT, SRC_PRE, SRC_ROWS };
+// Contraction indices k >= K multiply exact zeros (the last 16-wide k block is masked in registers); output columns
+// j past the real extent are computed from whatever the range-checked loads return and dropped by the epilogues.
+enum { SRC_NONE = 0, SRC_W, SRC_WT };
 struct BSrc {
     const float* p;
     long d2;
     int kind;
     int J1, J, K;
+    int Jt, Kc;                     // extents of the product: output columns (ones row included), contraction steps (bias column included)
     int ld, ld2;
     int hole0, hole;
-    unsigned lim;                   // SRC_W / SRC_PRE: floats readable from p (range of the buffer descriptor)
+    unsigned lim;                   // floats readable from p (range of the buffer descriptor)
 };
 
-// One 64 x 64 chunk (j0.., k0..) moves through 16 (+4) registers per thread.  LOAD: issue the global loads (unconditional:
-// nothing here waits for memory).  !LOAD: registers -> LDS chunk buffer wb, applying the zero / one fill and the
-// activation.  Thread (jq = tid >> 4, kq = tid & 15):
-//   direct kinds (W, PRE: global memory contiguous along k): rows j = jq + 16e, e < 4, columns k = 4kq..4kq+3 as ONE
-//     buffer_load_dwordx4 (dword-aligned; the descriptor's range check returns 0 past the arena, so no clamping) and ONE
-//     ds_write_b128; per-row offsets are scalar (soffset), so a chunk costs one address computation per thread;
-//   transposing kinds (WT, ROWS: contiguous along j), thread (w = tid >> 6, l = tid & 63), 16 scalar elements:
-//     j = (l & 7) + 8w + 32(e & 1), k = (l >> 3) + 8(e >> 1)  (8 consecutive j x 8 k per wave keep both the 32-B global
-//     segments and the LDS banks of the transposed store distinct); out-of-range elements read a clamped address.
-template <bool LOAD, int NW>
-__device__ __forceinline__ void chunk_io(float (&r)[16], float (&rb)[4], const BSrc& S, int j0, int k0, float* wb) {
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));       // opaque: keeps the per-element addresses of every call site from being hoisted
-                                        // out of the layer loops (hundreds of live registers otherwise)
-    const int w = tid >> 6, l = tid & 63;
-    const int jq = tid >> 4, kq = tid & 15;
-    const float* __restrict__ p = S.p;
-    if (S.kind == SRC_W || S.kind == SRC_PRE) {
-        const bool isw = S.kind == SRC_W;
-        const int kf = k0 + 4 * kq;                                  // contraction index of my first column
-        const int sh = (isw && kf >= S.hole0 + S.hole) ? S.hole : 0;   // (hole0 + hole is a multiple of 4: uniform per group)
-        const int c0 = kf - sh;                                      // its column in memory
-        if (LOAD) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(S.lim * 4u), 0x00020000);
-            const int vo = ((j0 + jq) * S.ld + c0) * 4, vb = ((int)S.d2 + j0 + jq) * 4;
+// ------------------------------------------------------------------------------ the contraction
+// A wave owns the 16-column tile col0 = 16 wave (+ 16 NW per pass) of a product for all RTE row tiles of the workgroup
+// and fetches its Bm fragments STRAIGHT from global memory / L2 into MFMA operand layout -- lane (c, q) holds
+// Bm[col0 + c][16 blk + 4q .. + 3], one 128-bit load per 16 contraction steps for the k-contiguous kinds, four 32-bit
+// loads for the transposing ones -- BPD blocks (one "group") ahead of their use, across pass and product boundaries too.
+// Nothing of the streamed operand goes through LDS and no barrier separates the k blocks: a product costs ONE workgroup
+// barrier (its A tile, written by the previous epilogue, must be complete).
+#define BPD 4
+#define ONES4 ((f32x4){1.f, 1.f, 1.f, 1.f})
+struct Stream {           // prefetch state carried from one product to the next
+    f32x4 bq[BPD];        // group 0 of this wave's first tile of the upcoming product
+    float bias;           //   (+ its bias entry, SRC_W)
+    int n;                // diagnostic build: stamps written so far
+};
+
+// Issue the loads of blocks blk0 .. blk0 + BPD - 1 of tile col0 of S into dst (+ the tile's bias entry, SRC_W).  KIND is
+// a compile-time copy of S.kind and every call issues the same number of loads whatever the extents are (blocks / tiles
+// past them read range-checked addresses and are never used): the compiler can then count outstanding loads exactly, and
+// a wait for the group that is needed now does not also wait for the groups issued after it.
+template <int KIND>
+__device__ __forceinline__ void group_load(f32x4 (&dst)[BPD], float& bias, const BSrc& S, int col0, int blk0) {
+    if (KIND == SRC_NONE) return;
+    int lane = threadIdx.x & 63;
+#ifndef MF_TRANSPARENT
+    asm volatile("" : "+v"(lane));      // opaque: keeps the per-lane addresses of every call site from being hoisted
+#endif
+    const int c = lane & 15, q = lane >> 4;
+    const int j = col0 + c;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.p, 0, (int)(S.lim * 4u), 0x00020000);
+    if (KIND == SRC_W) {
+        const int rowo = j * S.ld + 4 * q;
+        const int hend = S.hole0 + S.hole;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, e * 16 * NW * S.ld, 0));
-                r[4 * e] = t[0]; r[4 * e + 1] = t[1]; r[4 * e + 2] = t[2]; r[4 * e + 3] = t[3];
-                if (isw) rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vb, e * 16 * NW, 0));
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = j0 + jq + 4 * NW * e;
-                f32x4 o;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = kf + i, cc = c0 + i;
-                    float v;
-                    if (isw) {
-                        const bool ok = j < S.J && !(k >= S.hole0 && k < S.hole0 + S.hole);
-                        v = (ok && cc < S.K) ? r[4 * e + i] : (ok && cc == S.K) ? rb[e] : 0.f;
-                    } else {
-                        v = (k < S.K && j < S.J) ? r[4 * e + i] : (k < S.K && j == S.J) ? 1.f : 0.f;
-                    }
-                    o[i] = v;
-                }
-                *reinterpret_cast<f32x4*>(wb + (jq + 4 * NW * e) * LDC + 4 * kq) = o;
-            }
+        for (int u = 0; u < BPD; ++u) {
+            const int kf = 16 * (blk0 + u) + 4 * q;
+            const int sh = kf >= hend ? S.hole : 0;
+            dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (rowo + 16 * (blk0 + u) - sh) * 4, 0, 0));
         }
-    } else if (S.kind == SRC_WT) {
-        const int jl = (l & 7) + 8 * w, kl = l >> 3;
-        const int ja = j0 + jl, jb = ja + 8 * NW;
-        const int oj[2] = {min(ja, S.J - 1), min(jb, S.J - 1)};
-        const bool vj[2] = {ja < S.J, jb < S.J};
-        float* dst = wb + jl * LDC + kl;
+        bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ((int)S.d2 + j) * 4, 0, 0));
+    } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int k = k0 + kl + 8 * (e >> 1);
-            if (LOAD) r[e] = p[min(k, S.K - 1) * S.ld + oj[e & 1]];
-            else dst[8 * NW * (e & 1) * LDC + 8 * (e >> 1)] = (vj[e & 1] && k < S.K) ? r[e] : 0.f;
-        }
-    } else if (S.kind == SRC_ROWS) {
-        const int jl = (l & 7) + 8 * w, kl = l >> 3;
-        const bool two = S.J > S.J1;
-        const int ja = j0 + jl, jb = ja + 8 * NW;
-        // column offset inside a row of block a (stride ld) or block b (stride ld2, at p + d2)
-        const bool inb[2] = {two && ja >= S.J1, two && jb >= S.J1};
-        const long cj[2] = {inb[0] ? S.d2 + (min(ja, S.J - 1) - S.J1) : (long)min(ja, S.J1 - 1),
-                            inb[1] ? S.d2 + (min(jb, S.J - 1) - S.J1) : (long)min(jb, S.J1 - 1)};
-        const int rs[2] = {inb[0] ? S.ld2 : S.ld, inb[1] ? S.ld2 : S.ld};
-        const int vj[2] = {ja < S.J ? 1 : ja == S.J ? 2 : 0, jb < S.J ? 1 : jb == S.J ? 2 : 0};
-        float* dst = wb + jl * LDC + kl;
+        for (int u = 0; u < BPD; ++u) {
+            const int vo = ((16 * (blk0 + u) + 4 * q) * S.ld + j) * 4;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int k = k0 + kl + 8 * (e >> 1);
-            if (LOAD) r[e] = p[cj[e & 1] + (long)(min(k, S.K - 1) * rs[e & 1])];
-            else dst[8 * NW * (e & 1) * LDC + 8 * (e >> 1)] = k < S.K ? (vj[e & 1] == 1 ? r[e] : vj[e & 1] == 2 ? 1.f : 0.f) : 0.f;
+            for (int x = 0; x < 4; ++x)
+                dst[u][x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, x * S.ld * 4, 0));
         }
     }
 }
-
-// ------------------------------------------------------------------------------ the contraction
-struct Stream {           // chunk pipeline state carried from one product to the next
-    float r[16];          // prefetched first chunk of the next product
-    float rb[4];          //   (+ its bias entries)
-    float* wbuf;          // two chunk buffers
-    int par;              // which one the next chunk goes to
-    int n;                // diagnostic build: stamps written so far
-};
-template <int NW>
-__device__ __forceinline__ void chunk_load(Stream& St, const BSrc& S, int j0, int k0) {
-    if (S.kind != SRC_NONE) chunk_io<true, NW>(St.r, St.rb, S, j0, k0, nullptr);
+// first prefetch of a kernel: group 0 of this wave's first tile of product S (nw: waves of a chain's group, k_chain)
+template <int KIND>
+__device__ __forceinline__ void stream_begin(Stream& St, const BSrc& S, int nw = 1 << 20) {
+    St.bias = 0.f;
+#pragma unroll
+    for (int u = 0; u < BPD; ++u) St.bq[u] = ZERO4;
+    group_load<KIND>(St.bq, St.bias, S, 16 * (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) % nw), 0);
 }
-template <int NW>
-__device__ __forceinline__ void chunk_store(Stream& St, const BSrc& S, int j0, int k0, float* wb) {
-    chunk_io<false, NW>(St.r, St.rb, S, j0, k0, wb);
+// a k block that reaches past the real contraction extent: those indices become exact zeros, the bias enters
+template <int KIND>
+__device__ __forceinline__ f32x4 frag_last(const BSrc& S, f32x4 b, int kf, float bias) {
+    if (KIND == SRC_W) {
+        const int sh = kf >= S.hole0 + S.hole ? S.hole : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = kf + i - sh;
+            b[i] = cc < S.K ? b[i] : cc == S.K ? bias : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = kf + i < S.K ? b[i] : 0.f;
+    }
+    return b;
 }
 
-// out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RT (RT <= RTE row tiles), j < Jn, k < Kc.
-// RTE (1, 2 or 4) fixes the wave -> tile map at compile time: wave w owns row tile w % RTE and the NTW = RTE column
-// tiles (w / RTE) + (4 / RTE) * t of every 64-column block, so the MFMA loop has no data-dependent control flow; tiles
-// and k-steps beyond the real extents multiply zero-filled chunk rows / columns (the epilogue drops them).
-// On entry St.r holds chunk (0, 0) of S; on exit it holds chunk (0, 0) of `next` (if any).
+// out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RT (RT <= RTE row tiles), j < S.Jt, k < S.Kc; A in LDS (row stride lda).
+// KIND = S.kind, NKIND = next.kind (compile-time copies).  On entry St holds group 0 of this wave's first tile of S; on
+// exit that of `next`, whose loads are issued when this product's last pass STARTS -- a whole product ahead of their use.
 // epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0), fetched
 // BEFORE the contraction so that global operands of the epilogue (activation derivatives of the dgrad mask) arrive under it.
 struct NoPre { __device__ __forceinline__ f32x4 operator()(int, int) const { return ZERO4; } };
-template <int RTE, int NW, class EPI, class PRE = NoPre>
-__device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, int Jn, int Kc, const BSrc& next,
+template <int RTE, int NW, int KIND, int NKIND, class EPI, class PRE = NoPre>
+__device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, const BSrc& next,
                                           Stream& St, EPI&& epi, PRE&& pre = PRE()) {
     GEOM(NW);
-    constexpr int WN = NW / RTE, NTW = RTE;
+    constexpr int NA = RTE == 1 ? 2 : 1;          // one row tile: two accumulators break the dependent MFMA chain
+    constexpr int NK = NKIND == SRC_NONE ? KIND : NKIND;      // nothing follows: the same number of (out-of-range) loads
     int tid = threadIdx.x;
+#ifndef MF_TRANSPARENT
     asm volatile("" : "+v"(tid));
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, q = lane >> 4;
-    const int rt = wave % RTE, cg = wave / RTE;
-    const bool active = rt < RT;
-    const int K16 = up16(Kc);
-    for (int j0 = 0; j0 < Jn; j0 += NCH) {
-        f32x4 acc[NTW], aux[NTW];
+#endif
+    // (k_chain runs several chains as groups of NW waves in one workgroup: the tile map is relative to the group)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) % NW, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int nblk = up16(S.Kc) >> 4, ngrp = (nblk + BPD - 1) / BPD;
+    const int kmask = KIND == SRC_W ? S.Kc - 1 : S.K;     // k blocks reaching past it are masked (SRC_W: only the last one)
+    BSrc nsrc = next;
+    if (NKIND == SRC_NONE) { nsrc = S; nsrc.lim = 0; }
+    MSTAMPF(2);
+    __syncthreads();                               // the A tile is complete
+    MSTAMPF(3);
+    if (16 * wave >= S.Jt) {                       // no tile of this product is mine
+        group_load<NK>(St.bq, St.bias, nsrc, 16 * wave, 0);
+        return;
+    }
+    for (int col0 = 16 * wave; col0 < S.Jt; col0 += NCH) {
+        // my tile of the next pass, else of the following product: in flight under this whole tile
+        f32x4 nx[BPD];
+        float nbias = 0.f;
+        if (col0 + NCH < S.Jt) group_load<KIND>(nx, nbias, S, col0 + NCH, 0);
+        else group_load<NK>(nx, nbias, nsrc, 16 * wave, 0);
+        f32x4 acc[RTE][NA], aux[RTE];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) { acc[t] = ZERO4; aux[t] = active ? pre(rt, j0 + 16 * (cg + WN * t)) : ZERO4; }
-        for (int k0 = 0; k0 < K16; k0 += KCH) {
-            const int nk = min(KCH, K16 - k0) >> 4;
-            float* wb = St.wbuf + St.par * CHUNK;
-            St.par ^= 1;
-            MSTAMP(1);
-            chunk_store<NW>(St, S, j0, k0, wb);
-            MSTAMP(2);
-            __syncthreads();
-            MSTAMP(3);
-            // prefetch: next k chunk, else next column block, else the following product's first chunk
-            if (k0 + KCH < K16) chunk_load<NW>(St, S, j0, k0 + KCH);
-            else if (j0 + NCH < Jn) chunk_load<NW>(St, S, j0 + NCH, 0);
-            else chunk_load<NW>(St, next, 0, 0);
-            MSTAMP(4);
-            if (active) {
-                const float* ap = A + (16 * rt + c) * lda + k0 + 4 * q;
-                const float* bp = wb + (16 * cg + c) * LDC + 4 * q;
-                // operands of k-step i+1 are read before the MFMAs of step i
-                f32x4 av = *reinterpret_cast<const f32x4*>(ap), bv[NTW];
+        for (int rt = 0; rt < RTE; ++rt) {
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp + t * WN * 16 * LDC);
-                for (int i = 0; i < nk; ++i) {
-                    const f32x4 a0 = av;
-                    f32x4 b0[NTW];
+            for (int a = 0; a < NA; ++a) acc[rt][a] = ZERO4;
+            aux[rt] = rt < RT ? pre(rt, col0) : ZERO4;
+        }
+        const float bias = St.bias;
+        const float* ap = A + c * lda + 4 * q;
+        // one group of k blocks from the fragments in cur; the A fragments of the whole group are read first (rows past
+        // the operand's width are finite LDS contents that meet exact zeros)
+        auto group = [&](const f32x4 (&cur)[BPD], int g) {
+            constexpr bool AHEAD = RTE == 1;       // (more row tiles: the fragments of a whole group would spill)
+            f32x4 a[BPD][RTE];
+            if (AHEAD) {
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t) b0[t] = bv[t];
-                    const int in = min(i + 1, nk - 1) * 16;       // (the last step re-reads itself: branch-free)
-                    av = *reinterpret_cast<const f32x4*>(ap + in);
+                for (int u = 0; u < BPD; ++u)
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t) bv[t] = *reinterpret_cast<const f32x4*>(bp + t * WN * 16 * LDC + in);
+                    for (int rt = 0; rt < RTE; ++rt) a[u][rt] = *reinterpret_cast<const f32x4*>(ap + 16 * rt * lda + 16 * (g * BPD + u));
+            }
 #pragma unroll
-                    for (int x = 0; x < 4; ++x)
+            for (int u = 0; u < BPD; ++u) {
+                const int blk = g * BPD + u;
+                if (blk < nblk) {
+                    f32x4 b = cur[u];
+                    if (16 * blk + 16 > kmask) b = frag_last<KIND>(S, b, 16 * blk + 4 * q, bias);
 #pragma unroll
-                        for (int t = 0; t < NTW; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[x], b0[t][x], acc[t], 0, 0, 0);
+                    for (int rt = 0; rt < RTE; ++rt)
+                        if (rt < RT) {
+                            const f32x4 av = AHEAD ? a[u][rt] : *reinterpret_cast<const f32x4*>(ap + 16 * rt * lda + 16 * blk);
+#pragma unroll
+                            for (int x = 0; x < 4; ++x)
+                                acc[rt][x % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], b[x], acc[rt][x % NA], 0, 0, 0);
+                        }
                 }
             }
-        }
-        MSTAMP(5);
-        if (active) {
+        };
+        for (int g = 0; g + 1 < ngrp; ++g) {       // steady state: the next group of this tile is in flight under this one
+            f32x4 cur[BPD];
+            float nob;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) epi(rt, j0 + 16 * (cg + WN * t), acc[t], aux[t]);
+            for (int u = 0; u < BPD; ++u) cur[u] = St.bq[u];
+            group_load<KIND>(St.bq, nob, S, col0, (g + 1) * BPD);
+            group(cur, g);
         }
-        MSTAMP(6);
+        {   // last group.  The epilogue's global operands are older than every load still outstanding but the next tile's:
+            // waiting for them HERE is cheap, in the epilogue the compiler could not tell.
+#pragma unroll
+            for (int rt = 0; rt < RTE; ++rt) asm volatile("" ::"v"(aux[rt]));
+            MSTAMPF(31);
+            f32x4 cur[BPD];
+#pragma unroll
+            for (int u = 0; u < BPD; ++u) cur[u] = St.bq[u];
+            group(cur, ngrp - 1);
+        }
+        MSTAMPF(5);
+#pragma unroll
+        for (int rt = 0; rt < RTE; ++rt)
+            if (rt < RT) epi(rt, col0, NA == 2 ? acc[rt][0] + acc[rt][NA - 1] : acc[rt][0], aux[rt]);
+        MSTAMPF(6);
+#pragma unroll
+        for (int u = 0; u < BPD; ++u) St.bq[u] = nx[u];
+        St.bias = nbias;
     }
 }
 
@@ -281,16 +302,17 @@ __device__ __forceinline__ BSrc src_none() {
 // forward operand of layer li
 __device__ __forceinline__ BSrc src_w(const Layout& L, const MlpDesc& D, const float* P, int li, bool holey) {
     BSrc S = src_none();
-    S.kind = SRC_W; S.p = P + D.w_off[li]; S.d2 = D.b_off[li] - D.w_off[li];
-    S.J1 = S.J = D.dout[li]; S.K = D.din[li]; S.ld = D.din[li]; S.lim = (unsigned)(L.n_params - D.w_off[li]);
+    S.kind = SRC_W; S.p = P + D.lay[li].w_off; S.d2 = D.lay[li].b_off - D.lay[li].w_off;
+    S.J1 = S.J = D.lay[li].dout; S.K = D.lay[li].din; S.ld = D.lay[li].din; S.lim = (unsigned)(L.n_params - D.lay[li].w_off);
     if (holey) { S.hole0 = L.dd; S.hole = L.uoff - L.dd; }
+    S.Jt = S.J; S.Kc = S.K + S.hole + 1;
     return S;
 }
 
 // One MLP forward.  `in` (LDS, stride ld_in) holds the layer-0 input with a constant-1 column after its Kin0
 // columns; `holey`: the input tile is [x | pad | u | 1] and W's columns skip the pad.  head(rt, col0, acc) receives
 // the output layer's tiles.  `next`: first streamed operand of whatever product follows this MLP.
-template <int RTE, int NW, class HEAD>
+template <int RTE, int NW, int NEXTK, class HEAD>
 __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const MlpDesc& D, const float* in, int ld_in, int Kin0, bool holey,
                                         const BSrc& next, Stream& St, HEAD&& head) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
@@ -301,16 +323,15 @@ __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const 
         const BSrc S = src_w(L, D, X.P, li, holey && li == 0);
         BSrc nx = next;
         if (!last) nx = src_w(L, D, X.P, li + 1, false);
-        const int Kc = (li == 0 ? Kin0 : L.H) + 1;
         MSTAMP(7);
-        const int N = D.dout[li];
+        const int N = D.lay[li].dout;
         if (last) {
-            tile_gemm<RTE, NW>(cur, ldc, RTE, S, N, Kc, nx, St, head);
+            tile_gemm<RTE, NW, SRC_W, NEXTK>(cur, ldc, RTE, S, nx, St, head);
         } else {
             float* dst = (li & 1) ? X.h1 : X.h0;
-            float* actT = X.wsm + D.pre_off[li] + X.row0;
-            float* derT = X.wsm + D.der_off[li] + X.row0;
-            tile_gemm<RTE, NW>(cur, ldc, RTE, S, N, Kc, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+            float* actT = X.wsm + D.lay[li].pre_off + X.row0;
+            float* derT = X.wsm + D.lay[li].der_off + X.row0;
+            tile_gemm<RTE, NW, SRC_W, SRC_W>(cur, ldc, RTE, S, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                 const int n = col0 + c;
                 if (n < N) {
                     const int r0 = 16 * rt + 4 * q;
@@ -341,8 +362,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GEOM(NW);
     const int TR = L.tr;
-    float* wbuf = smem;
-    float* xin = wbuf + 2 * CHUNK;          // [x | pad | u | 1 | 0..]
+    float* xin = smem;                      // [x | pad | u | 1 | 0..]
     float* h0 = xin + TR * L.ldx;
     float* h1 = h0 + TR * L.ldh;
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
@@ -356,11 +376,11 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
     const bool enc = m != IVAE_MLP_LOGL;
 
     Stream St;
-    St.wbuf = wbuf; St.par = 0; St.n = 0;
+    St.n = 0;
+    stream_begin<SRC_W>(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0));
     MSTAMP(100);
-    chunk_load<NW>(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), 0, 0);
 
-    for (int i = 4 * tid; i < L.smem_enc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(xin + i) = ZERO4;
+    for (int i = 4 * tid; i < L.smem_enc / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(xin + i) = ZERO4;
     __syncthreads();
     {   // input rows -> LDS: a wave per row, lanes over the columns, four loads in flight (no division, no load
         // waited for one by one)
@@ -384,6 +404,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
             }
         }
     }
+    MSTAMP(101);
     for (int r = tid; r < TR; r += NT) {
         xin[r * L.ldx + Kx] = 1.f;
         if (L.L > 1) { h0[r * L.ldh + L.H] = 1.f; h1[r * L.ldh + L.H] = 1.f; }
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
     FwdCtx X;
     X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = h0; X.h1 = h1;
     float* out = wsm + (m == IVAE_MLP_G ? L.ws.g : m == IVAE_MLP_LOGV ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
-    mlp_fwd<RTE, NW>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
+    mlp_fwd<RTE, NW, SRC_NONE>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
                  [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                      const int n = col0 + c;
                      if (n < L.dl) {
@@ -412,6 +433,7 @@ struct BwdCtx {
     float* wsm;
     float* slab;
     int row0, nrows, TR;
+    int np;                // parameters of a model (range of the weight loads)
     float* d0;             // delta tiles, row-major (TR, ldd)
     float* d1;
 };
@@ -419,49 +441,36 @@ struct BwdCtx {
 // Streamed operand of the input-gradient product of layer li: W^T.
 __device__ __forceinline__ BSrc dgrad_src(const BwdCtx& X, const MlpDesc& D, int li) {
     BSrc S = src_none();
-    S.kind = SRC_WT; S.p = X.P + D.w_off[li]; S.J1 = S.J = D.din[li]; S.K = D.dout[li]; S.ld = D.din[li];
+    S.kind = SRC_WT; S.p = X.P + D.lay[li].w_off; S.J1 = S.J = D.lay[li].din; S.K = D.lay[li].dout; S.ld = D.lay[li].din;
+    S.lim = (unsigned)(X.np - D.lay[li].w_off);
+    S.Jt = S.J; S.Kc = S.K;
     return S;
 }
-// Streamed operand of the weight-gradient product of layer li: the layer's input, transposed (hidden activations from
-// the workspace, or the layer-0 input rows in_a (width na) followed by in_b (width nb) from global memory).
-__device__ __forceinline__ BSrc wgrad_src(const Layout& L, const BwdCtx& X, const MlpDesc& D, int li, const float* in_a, int na,
-                                          const float* in_b, int nb) {
-    BSrc S = src_none();
-    if (li > 0) {
-        S.kind = SRC_PRE; S.p = X.wsm + D.pre_off[li - 1] + X.row0; S.J1 = S.J = D.din[li]; S.K = X.nrows; S.ld = L.Bp;
-        { const long lim = L.ws.per_model - (D.pre_off[li - 1] + X.row0); S.lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
-    } else {
-        S.kind = SRC_ROWS; S.p = in_a; S.d2 = in_b ? in_b - in_a : 0L; S.J1 = na; S.J = na + nb; S.K = X.nrows;
-        S.ld = na; S.ld2 = nb;
-    }
-    return S;
-}
-
 // Input-gradient chain of one MLP for a row tile.  On entry X.d0 holds dLoss/d(output) (rows >= nrows zero) and the
-// caller has stored it feature-major at D.dlt_off[L-1].  Every hidden layer's delta goes to the workspace feature-major
-// (D.dlt_off[li], (dout, Bp)): the weight gradients -- which nothing in this chain waits for -- are formed from those by
+// caller has stored it feature-major at D.lay[L-1].dlt_off.  Every hidden layer's delta goes to the workspace feature-major
+// (D.lay[li].dlt_off, (dout, Bp)): the weight gradients -- which nothing in this chain waits for -- are formed from those by
 // k_wgrad, one workgroup per (row tile, layer), after the chains.  When dx_out != null the gradient with respect to the
 // MLP's input is left there (LDS, stride ld_dx).
 template <int RTE, int NW>
-__device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const MlpDesc& D, float* dx_out, int ld_dx, const BSrc& next,
-                                        Stream& St) {
+__device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const MlpDesc& D, float* dx_out, int ld_dx, Stream& St) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int n_prod = dx_out ? L.L : L.L - 1;
     int cur = 0;
     for (int t = 0; t < n_prod; ++t) {
         const int li = L.L - 1 - t;
-        const int N = D.dout[li], K = D.din[li];
+        const int K = D.lay[li].din;
         const BSrc S = dgrad_src(X, D, li);
-        BSrc nx = next;
+        BSrc nx = src_none();
         if (t + 1 < n_prod) nx = dgrad_src(X, D, li - 1);
         MSTAMP(7);
         // dX[r][k] = sum_n delta[r][n] * W[n][k]  (times act'(pre) for a hidden input)
         const float* dcur = cur ? X.d1 : X.d0;
         if (li > 0) {
             float* dnx = cur ? X.d0 : X.d1;
-            const float* derT = X.wsm + D.der_off[li - 1] + X.row0;
-            float* dltT = X.wsm + D.dlt_off[li - 1] + X.row0;
-            tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
+            const float* derT = X.wsm + D.lay[li - 1].der_off + X.row0;
+            float* dltT = X.wsm + D.lay[li - 1].dlt_off + X.row0;
+            const bool more = t + 1 < n_prod;
+            auto epi = [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
                 const int k = col0 + c;
                 if (k < K) {
                     const int r0 = 16 * rt + 4 * q;
@@ -473,13 +482,16 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                     }
                     *reinterpret_cast<f32x4*>(dltT + (size_t)k * L.Bp + r0) = o;
                 }
-            }, [&](int rt, int col0) {
+            };
+            auto pre = [&](int rt, int col0) {
                 const int k = min(col0 + c, K - 1);
                 return *reinterpret_cast<const f32x4*>(derT + (size_t)k * L.Bp + 16 * rt + 4 * q);
-            });
+            };
+            if (more) tile_gemm<RTE, NW, SRC_WT, SRC_WT>(dcur, L.ldd, RTE, S, nx, St, epi, pre);
+            else tile_gemm<RTE, NW, SRC_WT, SRC_NONE>(dcur, L.ldd, RTE, S, nx, St, epi, pre);
             cur ^= 1;
         } else {
-            tile_gemm<RTE, NW>(dcur, L.ldd, RTE, S, K, N, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+            tile_gemm<RTE, NW, SRC_WT, SRC_NONE>(dcur, L.ldd, RTE, S, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                 const int k = col0 + c;
                 if (k < K) {
 #pragma unroll
@@ -490,81 +502,180 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
     }
 }
 
-// Weight / bias gradient of ONE layer of one MLP for a row tile: dW[n][k] = sum_r delta[r][n] * in[r][k], column K of
-// the result is the bias gradient.  blockIdx.z = mlp * L + layer (mlp order f, g, logv, logl).  delta^T comes from the
-// workspace (written by k_dec / k_bwd_enc), the layer input streams through LDS as in every other product; the result
-// goes to the tile's gradient slab.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_wgrad(Layout L, const float* __restrict__ params, const float* __restrict__ x,
-                                                   const float* __restrict__ u, float* __restrict__ ws,
-                                                   float* __restrict__ slabs, long slab_stride) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    GEOM(NW);
-    const int TR = L.trw;                   // rows of this kernel's tiles (its own tiling: the contraction length)
-    float* wbuf = smem;
-    float* dT = wbuf + 2 * CHUNK;           // delta transposed (n, ldr)
-    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
-    const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
-    const int mi = blockIdx.z / L.L, li = blockIdx.z - mi * L.L;
-    const int m = mi == 0 ? IVAE_MLP_F : mi == 1 ? IVAE_MLP_G : mi == 2 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL;
-    const MlpDesc& D = L.mlp[m];
-    float* wsm = ws + (size_t)model * L.ws.per_model;
-    const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
-    const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
-    const float* zrows = wsm + L.ws.z + (size_t)row0 * L.dl;
-
-    BwdCtx X;
-    X.P = params + (size_t)model * L.n_params; X.wsm = wsm;
-    X.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.slab_ld;
-    X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = X.d1 = nullptr;
-    const float* in_a = m == IVAE_MLP_F ? zrows : m == IVAE_MLP_LOGL ? um : xm;
-    const int na = m == IVAE_MLP_F ? L.dl : m == IVAE_MLP_LOGL ? L.M : L.dd;
-    const float* in_b = (m == IVAE_MLP_G || m == IVAE_MLP_LOGV) ? um : nullptr;
-    const int nb = in_b ? L.M : 0;
-    const int N = D.dout[li], K = D.din[li];
-    const BSrc S = wgrad_src(L, X, D, li, in_a, na, in_b, nb);
-
-    Stream St;
-    St.wbuf = wbuf; St.par = 0; St.n = 1500;      // (diagnostic stamps of this kernel go to slots 1500..)
-    chunk_load<NW>(St, S, 0, 0);
-    for (int i = 4 * tid; i < L.smem_wg / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dT + i) = ZERO4;
-    __syncthreads();
-    const float* dlt = wsm + D.dlt_off[li] + row0;
-    {   // (TR is a power of two; four loads in flight)
-        const int sh = __ffs(TR) - 1, tot = N * TR;
-        for (int i0 = tid; i0 < tot; i0 += 4 * NT) {
-            float v[4];
+// Weight / bias gradients of every layer: dW[n][k] = sum_r delta[r][n] * in[r][k] over a tile of L.trw batch rows; column
+// K of the result is the bias gradient (the input's constant-1 column).  No LDS, no barrier: a one-wave workgroup owns a
+// block of WG_NT x WG_KT 16 x 16 tiles of one layer's gradient (16 accumulators) and fetches both operands straight from
+// global memory in MFMA layout -- delta^T from the feature-major deltas the chains left in the workspace, the layer input
+// from the feature-major activations (hidden layers: one 128-bit load per tile and 16 rows) or from the row-major
+// x / u / z (first layers: four 32-bit loads) -- one 16-row block (64 MFMAs) ahead of its use, a fixed number of loads
+// per block so that the waits are exact.  blockIdx.z enumerates (MLP, layer, k-tile group, n-tile group) in the MLP order
+// f, g, logv, logl; the result goes to the row tile's gradient slab.
+#define WG_PD 2
+#define WG_NT 4
+#define WG_KT 4
+struct WgradJob {
+    const float* dlt;       // delta^T (N, Bp) at this tile's first row
+    unsigned dlt_lim;
+    const float* actT;      // hidden input, feature-major (K, Bp), at this tile's first row   (layer > 0)
+    unsigned act_lim;
+    const float* in_a;      // first-layer input rows: block a (na columns), block b (nb columns)
+    const float* in_b;
+    int na, nb;
+    int N, K, Bp, nrows;
+    float* slab;            // this row tile's gradient slab (parameter layout)
+    int slab_bytes, w_off, b_off;
+};
+template <bool ROWS>
+__device__ __forceinline__ void wgrad_block(const WgradJob& J, int kt0, int nt0) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int c = lane & 15, q = lane >> 4;
+    const int nb = (J.nrows + 15) >> 4;        // 16-row blocks that hold rows of the batch
+    const int ktv = min(WG_KT, (J.K + 16) / 16 - kt0);         // k tiles of this job that exist
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)J.dlt, 0, (int)(J.dlt_lim * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)J.actT, 0, (int)(J.act_lim * 4u), 0x00020000);
+    const int last_row = J.nrows - 1;
+    int jj[WG_KT], rstride[WG_KT];             // input feature of my result column in k tile kt (== K: the constant-1 column)
+    const float* base[WG_KT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int idx = i0 + e * NT, n = idx >> sh, r = idx & (TR - 1);
-                v[e] = (idx < tot && r < nrows) ? dlt[(size_t)n * L.Bp + r] : 0.f;
+    for (int kt = 0; kt < WG_KT; ++kt) {
+        const int j = 16 * (kt0 + kt) + c;
+        jj[kt] = j;
+        const bool inb = j >= J.na;
+        base[kt] = inb ? J.in_b + min(j - J.na, max(J.nb - 1, 0)) : J.in_a + j;       // (j > K: clamped, dropped)
+        rstride[kt] = inb ? J.nb : J.na;
+    }
+    f32x4 acc[WG_NT][WG_KT], fa[WG_PD][WG_NT], fb[WG_PD][WG_KT];
+#pragma unroll
+    for (int t = 0; t < WG_NT; ++t)
+#pragma unroll
+        for (int kt = 0; kt < WG_KT; ++kt) acc[t][kt] = ZERO4;
+    auto load_blk = [&](int u, int blk) {
+        blk = min(blk, nb - 1);
+        const int ro = 16 * blk + 4 * q;
+#pragma unroll
+        for (int t = 0; t < WG_NT; ++t)
+            fa[u][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, ((16 * (nt0 + t) + c) * J.Bp + ro) * 4, 0, 0));
+#pragma unroll
+        for (int kt = 0; kt < WG_KT; ++kt) {
+            if (!ROWS) {
+                fb[u][kt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (jj[kt] * J.Bp + ro) * 4, 0, 0));
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) fb[u][kt][x] = base[kt][(long)min(ro + x, last_row) * rstride[kt]];
             }
+        }
+    };
+    WSTAMP(1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int idx = i0 + e * NT, n = idx >> sh, r = idx & (TR - 1);
-                if (idx < tot) dT[n * L.ldr + r] = v[e];
+    for (int u = 0; u < WG_PD; ++u) load_blk(u, u);
+    WSTAMP(2);
+#ifdef MF_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WSTAMP(3);
+#endif
+    for (int b0 = 0; b0 < nb; b0 += WG_PD) {
+#pragma unroll
+        for (int u = 0; u < WG_PD; ++u) {
+            const int blk = b0 + u;
+            f32x4 a[WG_NT], b[WG_KT];
+#pragma unroll
+            for (int t = 0; t < WG_NT; ++t) a[t] = fa[u][t];
+#pragma unroll
+            for (int kt = 0; kt < WG_KT; ++kt) b[kt] = jj[kt] == J.K ? ONES4 : fb[u][kt];
+            load_blk(u, blk + WG_PD);
+            if (blk < nb) {
+                if (16 * blk + 16 > J.nrows) {       // rows past the batch: both operands become exact zeros
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        const bool ok = 16 * blk + 4 * q + x < J.nrows;
+#pragma unroll
+                        for (int kt = 0; kt < WG_KT; ++kt) b[kt][x] = ok ? b[kt][x] : 0.f;
+#pragma unroll
+                        for (int t = 0; t < WG_NT; ++t) a[t][x] = ok ? a[t][x] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int kt = 0; kt < WG_KT; ++kt)
+                    if (kt < ktv) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+#pragma unroll
+                            for (int t = 0; t < WG_NT; ++t)
+                                acc[t][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][x], b[kt][x], acc[t][kt], 0, 0, 0);
+                    }
             }
         }
     }
-    // (the first tile_gemm's barrier orders these writes before any operand read)
-    float* gW = X.slab + D.w_off[li];
-    float* gB = X.slab + D.b_off[li];
-    const int NTl = (N + 15) >> 4;
-    for (int rc = 0; rc < NTl; rc += 4) {
-        BSrc nx = src_none();
-        if (rc + 4 < NTl) nx = S;
-        tile_gemm<4, NW>(dT + rc * 16 * L.ldr, L.ldr, min(4, NTl - rc), S, K + 1, TR, nx, St,
-                         [&](int rt, int col0, const f32x4& acc, const f32x4&) {
-                             const int k = col0 + c;
+    WSTAMP(4);
+    // results -> the slab: branch-free, an element outside the layer's (N, K + 1) gets an offset past the slab's range
+    // and the buffer store drops it
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)J.slab, 0, J.slab_bytes, 0x00020000);
 #pragma unroll
-                             for (int r = 0; r < 4; ++r) {
-                                 const int n = 16 * (rc + rt) + 4 * q + r;
-                                 if (n < N) {
-                                     if (k < K) gW[(size_t)n * K + k] = acc[r];
-                                     else if (k == K) gB[n] = acc[r];
-                                 }
-                             }
-                         });
+    for (int kt = 0; kt < WG_KT; ++kt) {
+        const int j = jj[kt];
+#pragma unroll
+        for (int t = 0; t < WG_NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * (nt0 + t) + 4 * q + r;
+                const int el = j < J.K ? J.w_off + n * J.K + j : J.b_off + n;
+                const int off = (n < J.N && j <= J.K) ? el * 4 : 0x7ffffff0;
+                const float val = acc[t][kt][r];       // (bit_cast of a vector element reads element 0: go through a scalar)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val), rg, off, 0, 0);
+            }
+    }
+    WSTAMP(5);
+}
+
+// jobs of one layer: groups of WG_KT k tiles (din + 1 columns) x groups of WG_NT n tiles
+__host__ __device__ __forceinline__ int wgrad_kgroups(int din) { return ((din + 16) / 16 + WG_KT - 1) / WG_KT; }
+__host__ __device__ __forceinline__ int wgrad_ngroups(int dout) { return ((dout + 15) / 16 + WG_NT - 1) / WG_NT; }
+
+#define WG_WAVES 4         // jobs (waves) per workgroup: the four waves of a workgroup sit on the four SIMDs of its CU
+__global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(Layout L, const float* __restrict__ x, const float* __restrict__ u,
+                                              float* __restrict__ ws, float* __restrict__ slabs, long slab_stride) {
+    WSTAMP(0);
+    const int model = blockIdx.y, row0 = blockIdx.x * L.trw, nrows = min(L.trw, L.B - row0);
+    // blockIdx.z -> (MLP, layer, k group, n group)
+    int m = -1, li = 0, job = 0;
+    {   // (static loop bounds over one 64-byte table: two wide scalar loads, not a dependent load per layer)
+        int z = blockIdx.z * WG_WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int mm = mi == 0 ? IVAE_MLP_F : mi == 1 ? IVAE_MLP_G : mi == 2 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL;
+#pragma unroll
+            for (int l = 0; l < IVAE_MAX_LAYERS; ++l) {
+                const int nj = L.wg_jobs[mi][l];
+                if (m < 0 && z < nj) { m = mm; li = l; job = z; }
+                z -= nj;
+            }
+        }
+    }
+    if (m < 0) return;
+    const MlpDesc& D = L.mlp[m];
+    const int kg = wgrad_kgroups(D.lay[li].din);
+    const int kt0 = (job % kg) * WG_KT, nt0 = (job / kg) * WG_NT;
+    float* wsm = ws + (size_t)model * L.ws.per_model;
+    WgradJob J;
+    J.N = D.lay[li].dout; J.K = D.lay[li].din; J.Bp = L.Bp; J.nrows = nrows;
+    J.dlt = wsm + D.lay[li].dlt_off + row0;
+    { const long lim = L.ws.per_model - (D.lay[li].dlt_off + row0); J.dlt_lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
+    J.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.slab_ld;
+    J.slab_bytes = L.n_params * 4; J.w_off = D.lay[li].w_off; J.b_off = D.lay[li].b_off;
+    J.actT = wsm; J.act_lim = 0; J.in_a = J.in_b = wsm; J.na = J.K; J.nb = 0;
+    if (li > 0) {
+        J.actT = wsm + D.lay[li - 1].pre_off + row0;
+        const long lim = L.ws.per_model - (D.lay[li - 1].pre_off + row0);
+        J.act_lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL);
+        wgrad_block<false>(J, kt0, nt0);
+    } else {
+        const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
+        const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : xm;
+        if (m == IVAE_MLP_F) { J.in_a = wsm + L.ws.z + (size_t)row0 * L.dl; J.na = L.dl; J.in_b = J.in_a; J.nb = 0; }
+        else if (m == IVAE_MLP_LOGL) { J.in_a = um; J.na = L.M; J.in_b = um; J.nb = 0; }
+        else { J.in_a = xm; J.na = L.dd; J.in_b = um; J.nb = L.M; }
+        wgrad_block<true>(J, kt0, nt0);
     }
 }
 
@@ -580,8 +691,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     GEOM(NW);
     const int TR = L.tr, lds = L.lds;
     const int ldt = max(L.ldh, L.ldd);
-    float* wbuf = smem;
-    float* t0 = wbuf + 2 * CHUNK;           // hidden tiles (forward) / delta tiles (backward)
+    float* t0 = smem;                       // hidden tiles (forward) / delta tiles (backward)
     float* t1 = t0 + TR * ldt;
     float* sz = t1 + TR * ldt;              // z with its constant-1 column
     float* sdz = sz + TR * lds;
@@ -596,14 +706,15 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
 
     BwdCtx B;
     B.P = P; B.wsm = wsm; B.slab = nullptr;
-    B.row0 = row0; B.nrows = nrows; B.TR = TR; B.d0 = t0; B.d1 = t1;
+    B.row0 = row0; B.nrows = nrows; B.TR = TR; B.np = L.n_params; B.d0 = t0; B.d1 = t1;
     const BSrc bwd_first = dgrad_src(B, DF, L.L - 1);
 
     Stream St;
-    St.wbuf = wbuf; St.par = 0; St.n = 0;
+    St.n = 0;
+    if (mode & 1) stream_begin<SRC_W>(St, src_w(L, DF, P, 0, false));
+    else stream_begin<SRC_WT>(St, bwd_first);
     MSTAMP(199);
-    chunk_load<NW>(St, (mode & 1) ? src_w(L, DF, P, 0, false) : bwd_first, 0, 0);
-    for (int i = 4 * tid; i < L.smem_dec / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(t0 + i) = ZERO4;
+    for (int i = 4 * tid; i < L.smem_dec / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(t0 + i) = ZERO4;
     __syncthreads();
 
     if (mode & 1) {
@@ -626,17 +737,18 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
         }
         FwdCtx X;
         X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = t0; X.h1 = t1;
-        mlp_fwd<RTE, NW>(L, X, DF, sz, lds, L.dl, false, (mode & 2) ? bwd_first : src_none(), St,
-                     [&](int rt, int col0, const f32x4& acc, const f32x4&) {
-                         const int n = col0 + c;
-                         if (n < L.dd) {
+        auto head = [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+            const int n = col0 + c;
+            if (n < L.dd) {
 #pragma unroll
-                             for (int r = 0; r < 4; ++r) {
-                                 const int row = 16 * rt + 4 * q + r;
-                                 if (row < nrows) fm[(size_t)row * L.dd + n] = acc[r];
-                             }
-                         }
-                     });
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + 4 * q + r;
+                    if (row < nrows) fm[(size_t)row * L.dd + n] = acc[r];
+                }
+            }
+        };
+        if (mode & 2) mlp_fwd<RTE, NW, SRC_WT>(L, X, DF, sz, lds, L.dl, false, bwd_first, St, head);
+        else mlp_fwd<RTE, NW, SRC_NONE>(L, X, DF, sz, lds, L.dl, false, src_none(), St, head);
         __syncthreads();
         // per-row Gaussian log-densities   (models/nets.py:306-314, 45-52): four lanes per row take every fourth
         // feature, then two xor-shuffles add the partial sums (fixed order)
@@ -674,7 +786,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     if (mode & 2) {
         // dLoss/df = -a*w*(x-f)/var, all TR rows (zero beyond the batch): the tiles may hold forward activations
         const float w = 1.f / (float)C.global_batch;
-        float* dltF = wsm + DF.dlt_off[L.L - 1] + row0;
+        float* dltF = wsm + DF.lay[L.L - 1].dlt_off + row0;
         __syncthreads();
         for (int idx = tid; idx < TR * L.dd; idx += NT) {
             const int r = idx / L.dd, k = idx - r * L.dd;
@@ -682,7 +794,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
             t0[r * L.ldd + k] = v;
             dltF[(size_t)k * L.Bp + r] = v;
         }
-        mlp_bwd<RTE, NW>(L, B, DF, sdz, lds, src_none(), St);
+        mlp_bwd<RTE, NW>(L, B, DF, sdz, lds, St);
         MSTAMP(201);
         __syncthreads();
         for (int idx = tid; idx < nrows * L.dl; idx += NT) {
@@ -726,8 +838,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
     extern __shared__ __attribute__((aligned(16))) float smem[];
     GEOM(NW);
     const int TR = L.tr;
-    float* wbuf = smem;
-    float* dA = wbuf + 2 * CHUNK;
+    float* dA = smem;
     float* dB = dA + TR * L.ldd;
     const int tid = threadIdx.x;
     const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
@@ -740,13 +851,15 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
 
     BwdCtx X;
     X.P = P; X.wsm = wsm; X.slab = nullptr;
-    X.row0 = row0; X.nrows = nrows; X.TR = TR; X.d0 = dA; X.d1 = dB;
-    float* dltT = wsm + L.mlp[m].dlt_off[L.L - 1] + row0;
+    X.row0 = row0; X.nrows = nrows; X.TR = TR; X.np = L.n_params; X.d0 = dA; X.d1 = dB;
+    float* dltT = wsm + L.mlp[m].lay[L.L - 1].dlt_off + row0;
 
     Stream St;
-    St.wbuf = wbuf; St.par = 0; St.n = 1000;      // (diagnostic stamps of this kernel go to slots 1000..)
-    chunk_load<NW>(St, L.L > 1 ? dgrad_src(X, L.mlp[m], L.L - 1) : src_none(), 0, 0);
-    for (int i = 4 * tid; i < L.smem_benc / 4 - 2 * CHUNK; i += 4 * NT) *reinterpret_cast<f32x4*>(dA + i) = ZERO4;
+    St.n = 0;
+    if (L.L > 1) stream_begin<SRC_WT>(St, dgrad_src(X, L.mlp[m], L.L - 1));
+    else stream_begin<SRC_NONE>(St, src_none());
+    St.n = 1000;                                  // (diagnostic stamps of this kernel go to slots 1000..)
+    for (int i = 4 * tid; i < L.smem_benc / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(dA + i) = ZERO4;
     __syncthreads();
     {   // head deltas: element idx = r * dl + k of the tile sits at (row0 * dl + idx) in every (B, dl) workspace tensor, so
         // the loads need no division; two elements per pass keep both elements' loads in flight
@@ -784,20 +897,255 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
             if (i1 < tot) put(i1, d1);
         }
     }
-    mlp_bwd<RTE, NW>(L, X, L.mlp[m], nullptr, 0, src_none(), St);
+    mlp_bwd<RTE, NW>(L, X, L.mlp[m], nullptr, 0, St);
     MSTAMP(202);
     // loss of the model (loss_out != null: no slab reduction follows, so k_reduce is not launched): one workgroup sums
     // the per-row terms with k_reduce's thread map and order (same bits)
     if (loss_out && blockIdx.x == 0 && blockIdx.z == 0) {
         __syncthreads();
-        if (tid < NR) wbuf[tid] = loss_partial(L, C, wsm, tid, NR);
+        float* red = dA;                    // (the delta tiles are dead; 2 TR ldd + 64 >= NR floats)
+        if (tid < NR) red[tid] = loss_partial(L, C, wsm, tid, NR);
         __syncthreads();
         for (int s = NR / 2; s > 0; s >>= 1) {
-            if (tid < s) wbuf[tid] += wbuf[tid + s];
+            if (tid < s) red[tid] += red[tid + s];
             __syncthreads();
         }
-        if (tid == 0) loss_out[model] = -wbuf[0] / (float)C.global_batch;
+        if (tid == 0) loss_out[model] = -red[0] / (float)C.global_batch;
     }
+}
+
+// Fused row chain: everything of a step that depends only on a tile's own rows, in ONE launch -- encoder / prior forward
+// (the g, logv, logl chains run concurrently as three groups of 4 waves, in lockstep through the same barriers),
+// reparameterisation, decoder forward, per-row log-densities, [mode bit 1] the decoder's input-gradient chain and
+// [mode bit 2, plain ELBO only: the pairwise terms couple the rows] the head deltas and the encoder / prior
+// input-gradient chains.  g, v, l, z, f and dLoss/dz stay in LDS between the stages; what other kernels read (k_wgrad:
+// activations and deltas; pairwise kernels and the loss: row tensors and per-row terms) goes to the workspace as before.
+// Replaces k_fwd_enc + k_dec (+ k_bwd_enc) where its tiles fit the LDS (Layout.smem_chain != 0): two launch boundaries
+// and every global round trip between the stages disappear from the dependent chain.
+#define CH_NW 4
+template <int RTE>
+__global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
+                                                          const float* __restrict__ x, const float* __restrict__ u,
+                                                          const float* __restrict__ eps, float* __restrict__ z_out,
+                                                          float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NW = CH_NW;
+    const int TR = L.tr, lds = L.lds, ldf = L.dd | 1;
+    const int ldt = max(L.ldh, L.ldd);
+    const int NT = blockDim.x;              // 64 * 4 * (number of encoder / prior chains)
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, q = lane >> 4;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6) / NW;          // 0: g (+ decoder), 1: logv, 2: logl
+    const int ngrp = L.M > 0 ? 3 : 2;
+    float* xin = smem;                      // [x | pad | u | 1 | 0..]
+    float* tiles = xin + TR * L.ldx;        // per group two (TR, ldt) tiles: hidden activations, then deltas
+    float* t0 = tiles + grp * 2 * TR * ldt;
+    float* t1 = t0 + TR * ldt;
+    float* sg = tiles + ngrp * 2 * TR * ldt;        // row tensors (TR, lds): g, v, l, z (+ constant-1 column), dLoss/dz, eps
+    float* sv = sg + TR * lds;
+    float* sl = sv + TR * lds;
+    float* sz = sl + TR * lds;
+    float* sdz = sz + TR * lds;
+    float* se = sdz + TR * lds;
+    float* sf = se + TR * lds;              // decoder output (TR, ldf)
+    const int model = blockIdx.y, row0 = blockIdx.x * TR, nrows = min(TR, L.B - row0);
+    const int m = grp == 0 ? IVAE_MLP_G : grp == 1 ? IVAE_MLP_LOGV : IVAE_MLP_LOGL;
+    const float* P = params + (size_t)model * L.n_params;
+    float* wsm = ws + (size_t)model * L.ws.per_model;
+    const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
+    const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : nullptr;
+    const float* em = eps + ((size_t)model * L.B + row0) * L.dl;
+    const int Kx = L.uoff + L.M;
+    const bool enc = m != IVAE_MLP_LOGL;
+    const MlpDesc& DF = L.mlp[IVAE_MLP_F];
+    BSrc idle = src_none();                 // what the groups without a product "prefetch": nothing (every load out of range)
+    idle.p = P; idle.lim = 0;
+
+    Stream St;
+    St.n = 0;
+    stream_begin<SRC_W>(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), NW);
+    MSTAMP(299);
+    for (int i = 4 * tid; i < L.smem_chain / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(smem + i) = ZERO4;
+    __syncthreads();
+    {   // input rows and noise -> LDS: a wave per row, lanes over the columns, four loads in flight
+        const int wv = tid >> 6, nwv = NT >> 6, W = L.dd + L.M;
+        for (int r = wv; r < nrows; r += nwv) {
+            const float* xr = xm + (size_t)r * L.dd;
+            const float* ur = um + (size_t)r * L.M - L.dd;          // indexed by k >= dd only (um is null when M == 0)
+            float* dst = xin + r * L.ldx;
+            for (int k0 = lane; k0 < W; k0 += 256) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + 64 * e;
+                    v[e] = k < L.dd ? xr[k] : k < W ? ur[k] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + 64 * e;
+                    if (k < W) dst[k < L.dd ? k : L.uoff + (k - L.dd)] = v[e];
+                }
+            }
+            if (lane < L.dl) se[r * lds + lane] = em[(size_t)r * L.dl + lane];
+        }
+    }
+    for (int r = tid; r < TR; r += NT) {
+        xin[r * L.ldx + Kx] = 1.f;
+        sz[r * lds + L.dl] = 1.f;
+        if (L.M == 0) for (int k = 0; k < L.dl; ++k) sl[r * lds + k] = 1.f;
+    }
+    if (L.L > 1)
+        for (int r = tid & (64 * NW - 1); r < TR; r += 64 * NW) { t0[r * L.ldh + L.H] = 1.f; t1[r * L.ldh + L.H] = 1.f; }
+    // (the first product's barrier orders these writes before any operand read)
+    MSTAMP(300);
+
+    // ---- encoder / prior forward: three chains in lockstep -> g, v, l rows (LDS + workspace)
+    {
+        FwdCtx X;
+        X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = t0; X.h1 = t1;
+        float* srow = grp == 0 ? sg : grp == 1 ? sv : sl;
+        float* out = wsm + (grp == 0 ? L.ws.g : grp == 1 ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
+        const BSrc nx = grp == 0 ? src_w(L, DF, P, 0, false) : idle;
+        mlp_fwd<RTE, NW, SRC_W>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, nx, St,
+                     [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+                         const int n = col0 + c;
+                         if (n < L.dl) {
+#pragma unroll
+                             for (int r = 0; r < 4; ++r) {
+                                 const int row = 16 * rt + 4 * q + r;
+                                 const float o = grp == 0 ? acc[r] : expf(acc[r]);
+                                 srow[row * lds + n] = o;
+                                 if (row < nrows) out[(size_t)row * L.dl + n] = o;
+                             }
+                         }
+                     });
+    }
+    __syncthreads();
+    MSTAMP(301);
+    // ---- reparameterisation z = eps*sqrt(v) + g      (models/nets.py:301-304, 145-149)
+    for (int idx = tid; idx < TR * L.dl; idx += NT) {
+        const int r = idx / L.dl, k = idx - r * L.dl;
+        float zz = 0.f;
+        if (r < nrows) {
+            const size_t o = (size_t)(row0 + r) * L.dl + k;
+            zz = se[r * lds + k] * sqrtf(sv[r * lds + k]) + sg[r * lds + k];
+            z_out[(size_t)model * L.B * L.dl + o] = zz;
+            wsm[L.ws.z + o] = zz;
+            if (L.M == 0) wsm[L.ws.l + o] = 1.f;
+        }
+        sz[r * lds + k] = zz;
+    }
+    // ---- decoder forward (group 0; the other groups keep step through the barriers) -> f (LDS + workspace)
+    BwdCtx B;
+    B.P = P; B.wsm = wsm; B.slab = nullptr;
+    B.row0 = row0; B.nrows = nrows; B.TR = TR; B.np = L.n_params; B.d0 = t0; B.d1 = t1;
+    float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
+    MSTAMP(302);
+    if (grp == 0) {
+        // (the hidden tiles still hold the g chain's activations: every column a product reads is rewritten by the
+        // previous one, the constant-1 column stays)
+        FwdCtx X;
+        X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = t0; X.h1 = t1;
+        auto head = [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+            const int n = col0 + c;
+            if (n < L.dd) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rt + 4 * q + r;
+                    sf[row * ldf + n] = acc[r];
+                    if (row < nrows) fm[(size_t)row * L.dd + n] = acc[r];
+                }
+            }
+        };
+        if (mode & 2) mlp_fwd<RTE, NW, SRC_WT>(L, X, DF, sz, lds, L.dl, false, dgrad_src(B, DF, L.L - 1), St, head);
+        else mlp_fwd<RTE, NW, SRC_NONE>(L, X, DF, sz, lds, L.dl, false, src_none(), St, head);
+    } else {
+        for (int li = 0; li < L.L; ++li) __syncthreads();
+    }
+    __syncthreads();
+    MSTAMP(303);
+    // ---- per-row Gaussian log-densities   (models/nets.py:306-314, 45-52): four lanes per row take every fourth
+    // feature, then two xor-shuffles add the partial sums (fixed order)
+    {
+        const int r = tid >> 2, part = tid & 3;
+        const bool live = r < nrows;                // (tid < 4 TR <= NT: whole waves take the same branch below)
+        const int rr = live ? r : 0;
+        const float dv = C.decoder_var;
+        const float logdv = logf(dv);
+        float lpx = 0.f, lqc = 0.f, lp = 0.f;
+        if (tid < 4 * TR) {
+            for (int k = part; k < L.dd; k += 4) {
+                const float df = xin[rr * L.ldx + k] - sf[rr * ldf + k];
+                lpx += -0.5f * (LOG2PI + logdv + df * df / dv);
+            }
+            for (int k = part; k < L.dl; k += 4) {
+                const float zz = sz[rr * lds + k], gg = sg[rr * lds + k], vv = sv[rr * lds + k], ll = sl[rr * lds + k];
+                const float dq = zz - gg;
+                lqc += -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
+                lp += -0.5f * (LOG2PI + logf(ll) + zz * zz / ll);
+            }
+            lpx += __shfl_xor(lpx, 1); lqc += __shfl_xor(lqc, 1); lp += __shfl_xor(lp, 1);
+            lpx += __shfl_xor(lpx, 2); lqc += __shfl_xor(lqc, 2); lp += __shfl_xor(lp, 2);
+            if (live && part == 0) {
+                wsm[L.ws.lpx + row0 + r] = lpx;
+                wsm[L.ws.lqc + row0 + r] = lqc;
+                wsm[L.ws.lp + row0 + r] = lp;
+            }
+        }
+    }
+    MSTAMP(304);
+    if (!(mode & 2)) return;
+    // ---- decoder input-gradient chain (group 0): layer deltas of f -> workspace, dLoss/dz -> sdz
+    const float w = 1.f / (float)C.global_batch;
+    {
+        // dLoss/df = -a*w*(x-f)/var, all TR rows (zero beyond the batch), over group 0's first tile (dead activations)
+        float* dF = tiles;
+        float* dltF = wsm + DF.lay[L.L - 1].dlt_off + row0;
+        for (int idx = tid; idx < TR * L.dd; idx += NT) {
+            const int r = idx / L.dd, k = idx - r * L.dd;
+            const float v = r < nrows ? -C.a * w * (xin[r * L.ldx + k] - sf[r * ldf + k]) / C.decoder_var : 0.f;
+            dF[r * L.ldd + k] = v;
+            dltF[(size_t)k * L.Bp + r] = v;
+        }
+    }
+    MSTAMP(305);
+    if (grp == 0) {
+        mlp_bwd<RTE, NW>(L, B, DF, sdz, lds, St);
+    } else {
+        for (int li = 0; li < L.L; ++li) __syncthreads();
+    }
+    __syncthreads();
+    if (!(mode & 4)) {
+        for (int idx = tid; idx < nrows * L.dl; idx += NT) {
+            const int r = idx / L.dl, k = idx - r * L.dl;
+            wsm[L.ws_dz + (size_t)(row0 + r) * L.dl + k] = sdz[r * lds + k];
+        }
+        return;
+    }
+    // ---- head deltas (plain ELBO: SURVEY.md §8 a-bwd) and the three encoder / prior input-gradient chains
+    MSTAMP(306);
+    if (L.L > 1) stream_begin<SRC_WT>(St, dgrad_src(B, L.mlp[m], L.L - 1), NW);
+    {
+        float* dltT = wsm + L.mlp[m].lay[L.L - 1].dlt_off + row0;
+        const int gt = tid & (64 * NW - 1);          // thread index inside my group
+        for (int idx = gt; idx < TR * L.dl; idx += 64 * NW) {
+            const int r = idx / L.dl, k = idx - r * L.dl;
+            float dlt = 0.f;
+            if (r < nrows) {
+                const float zz = sz[r * lds + k], gg = sg[r * lds + k], vv = sv[r * lds + k], ll = sl[r * lds + k];
+                const float dq = zz - gg;
+                const float rr = dq / vv;
+                const float Gz = sdz[r * lds + k] - w * (C.b * rr - C.d * zz / ll);
+                if (grp == 0) dlt = w * C.b * rr + Gz;
+                else if (grp == 1) dlt = -w * C.b * 0.5f * (1.f - dq * dq / vv) + Gz * 0.5f * se[r * lds + k] * sqrtf(vv);
+                else dlt = w * C.d * 0.5f * (1.f - zz * zz / ll);
+            }
+            t0[r * L.ldd + k] = dlt;
+            if (r < nrows) dltT[(size_t)k * L.Bp + r] = dlt;
+        }
+    }
+    MSTAMP(307);
+    mlp_bwd<RTE, NW>(L, B, L.mlp[m], nullptr, 0, St);
+    MSTAMP(308);
 }
 
 // Sum the per-tile slabs into grads and reduce the loss.  A block sums 64 parameters: wave g adds the tiles
@@ -867,7 +1215,7 @@ __global__ __launch_bounds__(64 * RED_W) void k_reduce(Layout L, IvaeCoef C, con
 template <int RTE, int NW>
 static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const float* params, const float* x, const float* u,
                            const float* eps, float* z_out, float* ws, float* grads, hipStream_t st) {
-    static SmemCache cur_enc = {}, cur_dec = {}, cur_benc = {}, cur_wg = {};
+    static SmemCache cur_enc = {}, cur_dec = {}, cur_benc = {};
     constexpr int NT = 64 * NW;
     const int nz = L.M > 0 ? 3 : 2;
     // gradient slabs: per-tile partials in the workspace, or the caller's gradient buffer itself when a model is one tile
@@ -881,9 +1229,7 @@ static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const f
         if ((e = set_smem((const void*)k_dec<RTE, NW>, L.smem_dec, cur_dec)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_dec<RTE, NW>), dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws);
     } else if (what == 5) {     // weight gradients of every layer of every MLP
-        if ((e = set_smem((const void*)k_wgrad<NW>, L.smem_wg, cur_wg)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_wgrad<NW>), dim3(L.n_wtiles, L.n_models, (nz + 1) * L.L), dim3(NT), L.smem_wg, st, L, params, x, u, ws,
-                           slabs, slab_stride);
+        hipLaunchKernelGGL(k_wgrad, dim3(L.n_wtiles, L.n_models, (L.wg_total + WG_WAVES - 1) / WG_WAVES), dim3(64 * WG_WAVES), 0, st, L, x, u, ws, slabs, slab_stride);
     } else {                    // encoder / prior input-gradient chains
         if ((e = set_smem((const void*)k_bwd_enc<RTE, NW>, L.smem_benc, cur_benc)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_bwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws,
@@ -911,10 +1257,31 @@ static hipError_t launch_phase(const Layout& L, const IvaeCoef& C, int what, con
 #undef GO
 }
 
-// grads_for_dec_bwd != null: also run the decoder's backward inside the decoder launch (the caller then passes
-// dec_bwd_done = true to launch_backward).
+template <int RTE>
+static hipError_t launch_chain_t(const Layout& L, const IvaeCoef& C, int mode, const float* params, const float* x, const float* u,
+                                 const float* eps, float* z_out, float* ws, hipStream_t st) {
+    static SmemCache cur = {};
+    hipError_t e;
+    if ((e = set_smem((const void*)k_chain<RTE>, L.smem_chain, cur)) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_chain<RTE>), dim3(L.n_tiles, L.n_models), dim3(64 * CH_NW * (L.M > 0 ? 3 : 2)), L.smem_chain, st, L, C, mode,
+                       params, x, u, eps, z_out, ws);
+    return hipGetLastError();
+}
+
+// grads_for_dec_bwd != null: also run the decoder's backward inside the forward launch (the caller then passes
+// dec_bwd_done = true to launch_backward); `full` (plain ELBO only): the encoder / prior input-gradient chains too, when
+// the fused row-chain kernel serves this layout.  *done (bits: 1 forward, 2 decoder backward, 4 encoder backward) says
+// what ran.
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                          const float* eps, float* z_out, float* ws, float* grads_for_dec_bwd, hipStream_t st) {
+                          const float* eps, float* z_out, float* ws, float* grads_for_dec_bwd, hipStream_t st, bool full,
+                          int* done) {
+    if (L.smem_chain) {
+        const int mode = 1 | (grads_for_dec_bwd ? 2 : 0) | (grads_for_dec_bwd && full && !C.pairwise ? 4 : 0);
+        if (done) *done = mode;
+        if (L.tr == 16) return launch_chain_t<1>(L, C, mode, params, x, u, eps, z_out, ws, st);
+        return launch_chain_t<2>(L, C, mode, params, x, u, eps, z_out, ws, st);       // (64-row tiles: smem_chain == 0)
+    }
+    if (done) *done = grads_for_dec_bwd ? 3 : 1;
     hipError_t e = launch_phase(L, C, 0, params, x, u, eps, z_out, ws, nullptr, st);
     if (e != hipSuccess) return e;
     return launch_phase(L, C, grads_for_dec_bwd ? 3 : 1, params, x, u, eps, z_out, ws, grads_for_dec_bwd, st);
@@ -922,15 +1289,21 @@ hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* param
 
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
                            const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st,
-                           const AdamFuse* fuse, bool* fused) {
+                           const AdamFuse* fuse, bool* fused, bool enc_bwd_done) {
     if (fused) *fused = false;
     hipError_t e;
     if (!dec_bwd_done && (e = launch_phase(L, C, 2, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
     const int nblk_p = L.n_wtiles > 1 ? (L.n_params + RED_P - 1) / RED_P : 0;
     // no slabs to sum: k_bwd_enc also reduces the loss and k_reduce is not launched
-    if ((e = launch_phase(L, C, 4, params, x, u, eps, nblk_p == 0 ? loss_out : nullptr, ws, grads, st)) != hipSuccess) return e;
+    if (!enc_bwd_done &&
+        (e = launch_phase(L, C, 4, params, x, u, eps, nblk_p == 0 ? loss_out : nullptr, ws, grads, st)) != hipSuccess)
+        return e;
     if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
-    if (nblk_p == 0) return hipSuccess;
+    if (nblk_p == 0 && !enc_bwd_done) return hipSuccess;
+    if (nblk_p == 0) {           // (the row-chain kernel has no view of the other tiles' rows: k_reduce's loss block alone)
+        hipLaunchKernelGGL(k_reduce<false>, dim3(1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out, AdamFuse{});
+        return hipGetLastError();
+    }
     if (fuse && L.n_models <= ADAM_MODELS_PER_LAUNCH) {
         hipLaunchKernelGGL(k_reduce<true>, dim3(nblk_p + 1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out, *fuse);
         if (fused) *fused = true;

@@ -4,7 +4,8 @@
 #include "layout.h"
 
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
-                          const float* eps, float* z_out, float* ws, float* grads_for_dec_bwd, hipStream_t st);
+                          const float* eps, float* z_out, float* ws, float* grads_for_dec_bwd, hipStream_t st, bool full = false,
+                          int* done = nullptr);
 // Adam update fused into the slab reduction of launch_backward (ivae_elbo_adam_steps): the thread that forms a gradient
 // element applies it, so a training step needs no separate optimiser launch.  Step sizes per model (at most
 // ADAM_MODELS_PER_LAUNCH models; the caller falls back to the separate launch beyond that).
@@ -29,7 +30,7 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
 // whose gradient needs no slab reduction has no k_reduce launch to ride on).
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
                            const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st,
-                           const AdamFuse* fuse = nullptr, bool* fused = nullptr);
+                           const AdamFuse* fuse = nullptr, bool* fused = nullptr, bool enc_bwd_done = false);
 hipError_t launch_pairwise(int n_rows, int n_cols, int d, const IvaeCoef& C, const float* z, const float* g,
                            const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz,
                            float* cg, float* cv, float* ws, int n_models, size_t mstride, hipStream_t st);

@@ -12,16 +12,21 @@
 size_t pairwise_ws_floats(int n_rows, int n_cols, int d);     // pairwise.hip
 static inline size_t ivae_pair_ws_floats(int n_rows, int n_cols, int d) { return pairwise_ws_floats(n_rows, n_cols, d); }
 
+// Everything a kernel needs about one nn.Linear sits in ONE 64-byte line of the kernel-argument segment: a product's
+// set-up costs one scalar-cache miss, not one per field (kernel arguments are read through the scalar cache, ~500 cycles a
+// cold line).
+struct alignas(64) LayerDesc {
+    int w_off, b_off;       // float offset of the layer's weight (out, in) / bias inside a model's arena
+    int din, dout;
+    int64_t pre_off;        // workspace offset of the hidden activations act(pre), feature-major (hidden, Bp)
+    int64_t der_off;        // ... and of the activation derivatives act'(pre), same layout
+    int64_t dlt_off;        // dLoss/d(pre-activation output) of the layer, feature-major (dout, Bp)
+    int pad[6];
+};
 struct MlpDesc {
+    LayerDesc lay[IVAE_MAX_LAYERS];
     int present;
     int in_dim, out_dim;
-    int w_off[IVAE_MAX_LAYERS];    // float offset of layer weight (out,in) inside a model's arena
-    int b_off[IVAE_MAX_LAYERS];
-    int din[IVAE_MAX_LAYERS];
-    int dout[IVAE_MAX_LAYERS];
-    int64_t pre_off[IVAE_MAX_LAYERS];  // workspace offset of the hidden activations act(pre), feature-major (hidden, Bp)
-    int64_t der_off[IVAE_MAX_LAYERS];  // ... and of the activation derivatives act'(pre), same layout
-    int64_t dlt_off[IVAE_MAX_LAYERS];  // dLoss/d(pre-activation output) of every layer, feature-major (dout, Bp)
 };
 
 struct Layout {
@@ -45,11 +50,18 @@ struct Layout {
     int ldx, ldh, lds;   // LDS row strides (4 * odd floats): input tile, hidden tiles, latent-width tiles
     int ldd, ldr, nT;    // delta tiles (row-major stride), transposed delta (stride, rows)
     int smem_enc, smem_dec, smem_benc, smem_wg;   // dynamic LDS bytes of k_fwd_enc, k_dec, k_bwd_enc, k_wgrad
+    int smem_chain;      // ... of the fused row-chain kernel k_chain; 0: its tiles do not fit, the three kernels above run
     int64_t ws_dz;       // (B, dl) dLoss/dz through the decoder (k_dec -> k_bwd_enc)
+    // k_wgrad's jobs (4 x 4 tile blocks) per layer, MLP order f, g, logv, logl: one 64-byte line to decode blockIdx.z from
+    alignas(64) unsigned short wg_jobs[4][IVAE_MAX_LAYERS];
+    int wg_total;        // their sum = k_wgrad's gridDim.z
 };
 
-#define IVAE_CHUNK_FLOATS(nw) (16 * (nw) * 68)      // one streamed operand chunk (elbo_mfma.hip)
 #define IVAE_LDS_LIMIT (160 * 1024)
+#ifndef IVAE_CHAIN_MIN_TILES
+#define IVAE_CHAIN_MIN_TILES 128
+#endif
+#define IVAE_CHAIN_LDS_LIMIT (96 * 1024)    // larger row-chain tiles leave the three-kernel path (one chain per workgroup)
 
 static inline int ivae_up16(int x) { return (x + 15) & ~15; }
 static inline int ivae_ld4o(int x) { return (((x + 3) >> 2) | 1) << 2; }     // smallest 4*odd >= x
@@ -59,7 +71,6 @@ static inline void ivae_tile_geometry(Layout& L, int tr, int nw) {
     const int wide = L.maxh;
     L.tr = tr;
     L.nw = nw;
-    const int chunk = IVAE_CHUNK_FLOATS(nw);
     L.ldx = ivae_ld4o(ivae_up16(L.uoff + L.M + 1));
     L.ldh = ivae_ld4o(ivae_up16(L.H + 1));
     L.lds = ivae_ld4o(ivae_up16(L.dl + 1));
@@ -67,10 +78,19 @@ static inline void ivae_tile_geometry(Layout& L, int tr, int nw) {
     L.nT = ivae_up16(wide);
     // +64 floats: k-steps past a tile's last column read (finite) neighbours; the last tile needs room for that
     const int ldt = L.ldh > L.ldd ? L.ldh : L.ldd;
-    L.smem_enc = 4 * (2 * chunk + tr * L.ldx + 2 * tr * L.ldh + 64);
-    L.smem_dec = 4 * (2 * chunk + 2 * tr * ldt + 2 * tr * L.lds + 64);
-    L.smem_benc = 4 * (2 * chunk + 2 * tr * L.ldd + 64);
-    L.smem_wg = 4 * (2 * chunk + L.nT * (16 + 4) + 64);      // with k_wgrad's smallest row tile; final value: ivae_make_layout
+    L.smem_enc = 4 * (tr * L.ldx + 2 * tr * L.ldh + 64);
+    L.smem_dec = 4 * (2 * tr * ldt + 2 * tr * L.lds + 64);
+    L.smem_benc = 4 * (2 * tr * L.ldd + 64 + 256);             // (+ the loss reduction's 256 partials)
+    L.smem_wg = 0;
+    {   // k_chain: input tile, two tiles per concurrent chain, seven row tensors (g, v, l, z, dz, eps; f)
+        const int ngrp = L.M > 0 ? 3 : 2;
+        const int64_t fl = (int64_t)tr * L.ldx + (int64_t)ngrp * 2 * tr * ldt + 6 * (int64_t)tr * L.lds + (int64_t)tr * (L.dd | 1) + 64;
+        L.smem_chain = 4 * fl <= IVAE_CHAIN_LDS_LIMIT ? (int)(4 * ((fl + 3) & ~(int64_t)3)) : 0;
+        // a launch that leaves most CUs empty runs faster as one chain per workgroup (three times the CUs, a third of
+        // the instruction stream on each): the fused kernel is for launches that fill the chip anyway
+        if (IVAE_CHAIN_MIN_TILES && (int64_t)((L.B + tr - 1) / tr) * L.n_models < IVAE_CHAIN_MIN_TILES) L.smem_chain = 0;
+        if (tr > 32) L.smem_chain = 0;            // (its 12-wave workgroups have 170 registers per lane: two row tiles at most)
+    }
 }
 
 static inline bool ivae_lds_over(const Layout& L) {
@@ -107,7 +127,8 @@ static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo
     L.B = d->batch; L.dd = d->data_dim; L.dl = d->latent_dim; L.M = d->aux_dim;
     L.H = d->n_layers > 1 ? d->hidden_dim : 0; L.L = d->n_layers; L.act = d->activation;
     L.slope = d->slope; L.n_models = d->n_models;
-    L.Bp = (L.B + 63) & ~63;
+    L.Bp = (((L.B + 63) >> 6) | 1) << 6;      // batch rounded up to an ODD multiple of 64: feature-major planes then start
+                                              // 256 B apart modulo 512 B instead of all on the same memory channels
     L.uoff = L.M > 0 ? (L.dd + 3) & ~3 : L.dd;
     int off = 0;
     int64_t wso = 0;
@@ -117,15 +138,15 @@ static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo
         if (m == IVAE_MLP_LOGL) { D.in_dim = L.M; D.out_dim = L.dl; }
         else if (m == IVAE_MLP_F) { D.in_dim = L.dl; D.out_dim = L.dd; }
         else { D.in_dim = L.dd + L.M; D.out_dim = L.dl; }
-        for (int li = 0; li < IVAE_MAX_LAYERS; ++li) { D.w_off[li] = D.b_off[li] = D.din[li] = D.dout[li] = 0; D.pre_off[li] = D.der_off[li] = D.dlt_off[li] = 0; }
+        for (int li = 0; li < IVAE_MAX_LAYERS; ++li) D.lay[li] = LayerDesc{};
         if (!D.present) continue;
         for (int li = 0; li < L.L; ++li) {
-            D.din[li] = li == 0 ? D.in_dim : L.H;
-            D.dout[li] = li == L.L - 1 ? D.out_dim : L.H;
-            D.w_off[li] = off; off += D.din[li] * D.dout[li];
-            D.b_off[li] = off; off += D.dout[li];
-            if (li < L.L - 1) { D.pre_off[li] = wso; wso += (int64_t)L.Bp * L.H; D.der_off[li] = wso; wso += (int64_t)L.Bp * L.H; }
-            D.dlt_off[li] = wso; wso += (int64_t)L.Bp * D.dout[li];
+            D.lay[li].din = li == 0 ? D.in_dim : L.H;
+            D.lay[li].dout = li == L.L - 1 ? D.out_dim : L.H;
+            D.lay[li].w_off = off; off += D.lay[li].din * D.lay[li].dout;
+            D.lay[li].b_off = off; off += D.lay[li].dout;
+            if (li < L.L - 1) { D.lay[li].pre_off = wso; wso += (int64_t)L.Bp * L.H; D.lay[li].der_off = wso; wso += (int64_t)L.Bp * L.H; }
+            D.lay[li].dlt_off = wso; wso += (int64_t)L.Bp * D.lay[li].dout;
         }
     }
     L.n_params = off;
@@ -151,7 +172,7 @@ static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo
     if (L.dd + L.M + 1 > jmax) jmax = L.dd + L.M + 1;
     if (L.dl + 1 > jmax) jmax = L.dl + 1;
     int nw = 4;
-    if ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 64) nw = jmax > 128 ? 16 : 8;
+    if ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 64) nw = 8;       // (16: the caller's choice only)
     if (d->waves) nw = d->waves;
     ivae_tile_geometry(L, tr, nw);
     while (ivae_lds_over(L) && (nw > 4 || tr > 16)) {
@@ -160,21 +181,28 @@ static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo
     }
     if (ivae_lds_over(L)) return IVAE_E_TOOLARGE;
     L.n_tiles = (L.B + tr - 1) / tr;
-    // k_wgrad's own row tiling: a weight gradient contracts over the batch rows, so its workgroups take as many rows
-    // (16 .. 256) as still leaves the chip two workgroups per CU (and fits 64 KB of LDS): fewer, longer contractions per
-    // chunk round trip and fewer slabs for k_reduce; launches too small to fill the chip keep 16-row tiles (measured)
+    // k_wgrad's own row tiling: a weight gradient contracts over the batch rows, so its one-wave jobs take as many rows
+    // (16 .. 256) as still gives every SIMD of the chip a job: longer contractions per job and fewer slabs for k_reduce
     {
-        const int64_t prods = (int64_t)(L.M > 0 ? 4 : 3) * L.L * L.n_models;
-        int trw = L.Bp < 256 ? L.Bp : 256;       // (Bp is a multiple of 64)
-        if (trw == 192) trw = 128;
-        auto smem = [&](int t) { return 4 * (2 * IVAE_CHUNK_FLOATS(L.nw) + L.nT * (t + 4) + 64); };
-        while (trw > 16 && ((int64_t)((L.B + trw - 1) / trw) * prods < 512 || smem(trw) > 64 * 1024)) trw >>= 1;
+        int64_t jobs = 0;                         // (MLP, layer, 4 x 4 tile block) jobs per row tile and model: k_wgrad's blockIdx.z
+        const int order[4] = {IVAE_MLP_F, IVAE_MLP_G, IVAE_MLP_LOGV, IVAE_MLP_LOGL};
+        for (int mi = 0; mi < 4; ++mi)
+            for (int li = 0; li < IVAE_MAX_LAYERS; ++li) {
+                const MlpDesc& D = L.mlp[order[mi]];
+                int nj = 0;
+                if (D.present && li < L.L) nj = (((D.lay[li].din + 16) / 16 + 3) / 4) * (((D.lay[li].dout + 15) / 16 + 3) / 4);
+                L.wg_jobs[mi][li] = (unsigned short)nj;        // (din, dout <= 4096: at most 65 * 64 blocks... checked below)
+                jobs += nj;
+            }
+        if (jobs > 60000) return IVAE_E_TOOLARGE;
+        L.wg_total = (int)jobs;
+        jobs *= L.n_models;
+        int trw = 256;
+        while (trw > 16 && (trw / 2 >= L.B + 15 || (int64_t)((L.B + trw - 1) / trw) * jobs < 1024)) trw >>= 1;
         if (d->wgrad_rows) trw = d->wgrad_rows;
-        while (trw > 16 && smem(trw) > IVAE_LDS_LIMIT) trw >>= 1;
-        if (smem(trw) > IVAE_LDS_LIMIT) return IVAE_E_TOOLARGE;
         L.trw = trw;
         L.ldr = trw + 4;
-        L.smem_wg = smem(trw);
+        L.smem_wg = 0;
         L.n_wtiles = (L.B + trw - 1) / trw;
     }
     L.slab_ld = (L.n_params + 3) & ~3;

@@ -76,7 +76,8 @@ def test_plain_workspace_is_linear_in_the_batch():
                                                             C.byref(n)), n.value))(C.c_size_t())
     (rc1, a), (rc2, b), (rc3, c) = size(4096, 0), size(40960, 0), size(409600, 0)
     assert rc1 == rc2 == rc3 == 0
-    assert abs(b / a - 10) < 0.2 and abs(c / a - 100) < 2, (a, b, c)
+    # (at most linear: a small batch uses shorter weight-gradient row tiles, i.e. relatively more gradient slabs)
+    assert b / a < 10.2 and abs(c / b - 10) < 0.2, (a, b, c)
     rc, q = size(40960, 1)
     assert rc == 0 and q > b + 100e6            # the pairwise scratch is what grows quadratically
     lay0, lay1 = _lib.IvaeWsLayout(), _lib.IvaeWsLayout()

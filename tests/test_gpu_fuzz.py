@@ -72,4 +72,7 @@ def test_random_shape_matches_fp64_oracle(seed):
             r_ = G[n]
             got = g[m, off:off + r_.size].reshape(r_.shape)
             off += r_.size
-            assert np.abs(got - r_).max() <= 2e-5 * max(np.abs(r_).max(), 1e-3), (seed, m, n, np.abs(got - r_).max(), np.abs(r_).max())
+            scale = np.abs(r_).max()
+            if r_.size < 4:     # a one- or two-element bias gradient is a sum over the batch that may cancel to far below its
+                scale = max(scale, np.abs(G[n.replace("bias", "weight")]).max())      # terms: its layer's weight gradient sets the scale
+            assert np.abs(got - r_).max() <= 2e-5 * max(scale, 1e-3), (seed, m, n, np.abs(got - r_).max(), np.abs(r_).max())

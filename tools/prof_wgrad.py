@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Phase anatomy of k_fwd_enc / k_dec / k_bwd_enc from the s_memtime stamps of the -DMF_PROF diagnostic build.
-usage: IVAE_AMD_LIB=build/libivae_mfprof.so prof_mfma.py cfg"""
+"""Stamps of one k_wgrad job (-DMF_PROF build, job blockIdx = (0, 0, MF_PROF_Z)): cycles between
+0 kernel entry, 1 job set-up done, 2 first loads issued, 3 they arrived, 4 contraction done, 5 stores issued.
+usage: IVAE_AMD_LIB=build/libivae_mfprof.so prof_wgrad.py cfg"""
 import ctypes as C
 import os
 import sys
@@ -11,8 +12,7 @@ import torch
 from ivae_amd import _lib, ops
 from time_generic import CFG
 
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg1g"
-which = sys.argv[2] if len(sys.argv) > 2 else "fwd"
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 dev = torch.device("cuda:0")
 shape, B, ck, N = CFG[name]
 ck = dict(ck, pairwise=False)
@@ -32,33 +32,13 @@ for _ in range(3):
 buf = torch.zeros(4000, dtype=torch.int64, device=dev)
 L = _lib.lib()
 L.ivae_debug_set_prof_mf.argtypes = [C.c_void_p]
-torch.cuda.synchronize()
-if which == "step":
-    z = torch.empty(B, shape.latent_dim, device=dev)
-    for _ in range(3):
-        ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws)
-    torch.cuda.synchronize()
-    L.ivae_debug_set_prof_mf(C.c_void_p(buf.data_ptr()))
-    ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws)
-elif which == "fwd":
-    L.ivae_debug_set_prof_mf(C.c_void_p(buf.data_ptr()))
-    ops.forward(shape, coef, params, x, u, eps, ws)
-else:
+for rep in range(3):
     ops.forward(shape, coef, params, x, u, eps, ws)
     torch.cuda.synchronize()
+    buf.zero_()
     L.ivae_debug_set_prof_mf(C.c_void_p(buf.data_ptr()))
     ops.backward(shape, coef, params, x, u, eps, ws)
-torch.cuda.synchronize()
-L.ivae_debug_set_prof_mf(C.c_void_p(0))
-b = buf.cpu().view(-1, 2).tolist()
-part = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # 0: slots 0..999 (k_fwd_enc / k_dec), 1: slots 1000.. (k_bwd_enc)
-b = b[1000 * part:1000 * part + 1000]
-b = [(i, t) for i, t in b if t]
-t0 = b[0][1]
-prev = t0
-tot = {}
-for i, t in b:
-    print(f"{i:4d} {t - t0:9d} +{t - prev:7d}")
-    tot[i] = tot.get(i, 0) + (t - prev)
-    prev = t
-print("sum by stamp id (ticks before it):", {k: v for k, v in sorted(tot.items())}, "total", prev - t0)
+    torch.cuda.synchronize()
+    L.ivae_debug_set_prof_mf(C.c_void_p(0))
+    b = buf.cpu().view(-1, 2)[1500:1506, 1].tolist()
+    print("k_wgrad job stamps (cycles from entry):", [t - b[0] for t in b])

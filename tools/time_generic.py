@@ -37,6 +37,9 @@ def flops_per_sample(shape, batch, pairwise):
 
 def main():
     dev = torch.device("cuda:0")
+    if os.environ.get("IVAE_TUNE"):          # "tile_rows,waves,wgrad_rows" (0 = the library's choice)
+        tr, nw, wr = (int(v) for v in os.environ["IVAE_TUNE"].split(","))
+        ops.TUNING.update(tile_rows=tr, waves=nw, wgrad_rows=wr)
     names = sys.argv[1:] or ["cfg0", "cfg1g", "cfg2", "cfg3", "cfg3p"]
     for name in names:
         shape, B, ck, N = CFG[name]
