@@ -119,9 +119,11 @@ struct BSrc {
 // barrier (its A tile, written by the previous epilogue, must be complete).
 #define BPD 4
 #define ONES4 ((f32x4){1.f, 1.f, 1.f, 1.f})
+#define MAX_RTE 4
 struct Stream {           // prefetch state carried from one product to the next
     f32x4 bq[BPD];        // group 0 of this wave's first tile of the upcoming product
     float bias;           //   (+ its bias entry, SRC_W)
+    f32x4 aux[MAX_RTE];   //   (+ the global operands of its epilogue, see tile_gemm's pre / pre_next)
     int n;                // diagnostic build: stamps written so far
 };
 
@@ -165,6 +167,8 @@ __device__ __forceinline__ void stream_begin(Stream& St, const BSrc& S, int nw =
     St.bias = 0.f;
 #pragma unroll
     for (int u = 0; u < BPD; ++u) St.bq[u] = ZERO4;
+#pragma unroll
+    for (int r = 0; r < MAX_RTE; ++r) St.aux[r] = ZERO4;
     group_load<KIND>(St.bq, St.bias, S, 16 * (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) % nw), 0);
 }
 // a k block that reaches past the real contraction extent: those indices become exact zeros, the bias enters
@@ -187,12 +191,20 @@ __device__ __forceinline__ f32x4 frag_last(const BSrc& S, f32x4 b, int kf, float
 // out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RT (RT <= RTE row tiles), j < S.Jt, k < S.Kc; A in LDS (row stride lda).
 // KIND = S.kind, NKIND = next.kind (compile-time copies).  On entry St holds group 0 of this wave's first tile of S; on
 // exit that of `next`, whose loads are issued when this product's last pass STARTS -- a whole product ahead of their use.
-// epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0), fetched
-// BEFORE the contraction so that global operands of the epilogue (activation derivatives of the dgrad mask) arrive under it.
+// epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0): global operands
+// of the epilogue (activation derivatives of the dgrad mask), fetched a whole TILE ahead like the fragments -- a pass
+// loads pre(rt, col0 + 16 NW) for the next one, the last pass pre_next(rt, first tile) for the following product; the
+// first product of a chain finds its own in St.aux (aux_begin).  pre and pre_next issue the same number of loads.
 struct NoPre { __device__ __forceinline__ f32x4 operator()(int, int) const { return ZERO4; } };
-template <int RTE, int NW, int KIND, int NKIND, class EPI, class PRE = NoPre>
+template <int RTE, class PRE>
+__device__ __forceinline__ void aux_begin(Stream& St, int nw, PRE&& pre) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) % nw;
+#pragma unroll
+    for (int rt = 0; rt < RTE; ++rt) St.aux[rt] = pre(rt, 16 * wave);
+}
+template <int RTE, int NW, int KIND, int NKIND, class EPI, class PRE = NoPre, class PREN = NoPre>
 __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, const BSrc& next,
-                                          Stream& St, EPI&& epi, PRE&& pre = PRE()) {
+                                          Stream& St, EPI&& epi, PRE&& pre = PRE(), PREN&& pre_next = PREN()) {
     GEOM(NW);
     constexpr int NA = RTE == 1 ? 2 : 1;          // one row tile: two accumulators break the dependent MFMA chain
     constexpr int NK = NKIND == SRC_NONE ? KIND : NKIND;      // nothing follows: the same number of (out-of-range) loads
@@ -211,20 +223,29 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
     MSTAMPF(3);
     if (16 * wave >= S.Jt) {                       // no tile of this product is mine
         group_load<NK>(St.bq, St.bias, nsrc, 16 * wave, 0);
+#pragma unroll
+        for (int rt = 0; rt < RTE; ++rt) St.aux[rt] = pre_next(rt, 16 * wave);
         return;
     }
     for (int col0 = 16 * wave; col0 < S.Jt; col0 += NCH) {
         // my tile of the next pass, else of the following product: in flight under this whole tile
-        f32x4 nx[BPD];
+        f32x4 nx[BPD], naux[RTE];
         float nbias = 0.f;
-        if (col0 + NCH < S.Jt) group_load<KIND>(nx, nbias, S, col0 + NCH, 0);
-        else group_load<NK>(nx, nbias, nsrc, 16 * wave, 0);
+        if (col0 + NCH < S.Jt) {
+            group_load<KIND>(nx, nbias, S, col0 + NCH, 0);
+#pragma unroll
+            for (int rt = 0; rt < RTE; ++rt) naux[rt] = pre(rt, col0 + NCH);
+        } else {
+            group_load<NK>(nx, nbias, nsrc, 16 * wave, 0);
+#pragma unroll
+            for (int rt = 0; rt < RTE; ++rt) naux[rt] = pre_next(rt, 16 * wave);
+        }
         f32x4 acc[RTE][NA], aux[RTE];
 #pragma unroll
         for (int rt = 0; rt < RTE; ++rt) {
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[rt][a] = ZERO4;
-            aux[rt] = rt < RT ? pre(rt, col0) : ZERO4;
+            aux[rt] = St.aux[rt];
         }
         const float bias = St.bias;
         const float* ap = A + c * lda + 4 * q;
@@ -282,6 +303,8 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
 #pragma unroll
         for (int u = 0; u < BPD; ++u) St.bq[u] = nx[u];
         St.bias = nbias;
+#pragma unroll
+        for (int rt = 0; rt < RTE; ++rt) St.aux[rt] = naux[rt];
     }
 }
 
@@ -456,6 +479,18 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int n_prod = dx_out ? L.L : L.L - 1;
     int cur = 0;
+    // activation derivatives of a product's output rows (the dgrad mask), feature-major in the workspace
+    struct DerLoad {
+        const float* p; int K, Bp, c, q;
+        __device__ __forceinline__ f32x4 operator()(int rt, int col0) const {
+            return *reinterpret_cast<const f32x4*>(p + (size_t)min(col0 + c, K - 1) * Bp + 16 * rt + 4 * q);
+        }
+    };
+    auto der_of = [&](int li) {          // of the hidden layer that feeds layer li (li >= 1); li < 1: any valid source, unused
+        const int l = max(li, 1);
+        return DerLoad{X.wsm + D.lay[l - 1].der_off + X.row0, D.lay[l].din, L.Bp, c, q};
+    };
+    if (L.L > 1) aux_begin<RTE>(St, NW, der_of(L.L - 1));
     for (int t = 0; t < n_prod; ++t) {
         const int li = L.L - 1 - t;
         const int K = D.lay[li].din;
@@ -467,7 +502,6 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
         const float* dcur = cur ? X.d1 : X.d0;
         if (li > 0) {
             float* dnx = cur ? X.d0 : X.d1;
-            const float* derT = X.wsm + D.lay[li - 1].der_off + X.row0;
             float* dltT = X.wsm + D.lay[li - 1].dlt_off + X.row0;
             const bool more = t + 1 < n_prod;
             auto epi = [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
@@ -483,12 +517,9 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                     *reinterpret_cast<f32x4*>(dltT + (size_t)k * L.Bp + r0) = o;
                 }
             };
-            auto pre = [&](int rt, int col0) {
-                const int k = min(col0 + c, K - 1);
-                return *reinterpret_cast<const f32x4*>(derT + (size_t)k * L.Bp + 16 * rt + 4 * q);
-            };
-            if (more) tile_gemm<RTE, NW, SRC_WT, SRC_WT>(dcur, L.ldd, RTE, S, nx, St, epi, pre);
-            else tile_gemm<RTE, NW, SRC_WT, SRC_NONE>(dcur, L.ldd, RTE, S, nx, St, epi, pre);
+            const DerLoad pre = der_of(li), pre_next = der_of(li - 1);
+            if (more) tile_gemm<RTE, NW, SRC_WT, SRC_WT>(dcur, L.ldd, RTE, S, nx, St, epi, pre, pre_next);
+            else tile_gemm<RTE, NW, SRC_WT, SRC_NONE>(dcur, L.ldd, RTE, S, nx, St, epi, pre, pre_next);
             cur ^= 1;
         } else {
             tile_gemm<RTE, NW, SRC_WT, SRC_NONE>(dcur, L.ldd, RTE, S, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
@@ -922,7 +953,9 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
 // activations and deltas; pairwise kernels and the loss: row tensors and per-row terms) goes to the workspace as before.
 // Replaces k_fwd_enc + k_dec (+ k_bwd_enc) where its tiles fit the LDS (Layout.smem_chain != 0): two launch boundaries
 // and every global round trip between the stages disappear from the dependent chain.
+#ifndef CH_NW
 #define CH_NW 4
+#endif
 template <int RTE>
 __global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
                                                           const float* __restrict__ x, const float* __restrict__ u,
@@ -966,26 +999,36 @@ __global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, 
     MSTAMP(299);
     for (int i = 4 * tid; i < L.smem_chain / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(smem + i) = ZERO4;
     __syncthreads();
-    {   // input rows and noise -> LDS: a wave per row, lanes over the columns, four loads in flight
+    {   // input rows and noise -> LDS: a wave takes two rows per pass, lanes over the columns: eight loads (+ two of the
+        // noise) in flight, one memory round trip for a 16- or 24-row tile
         const int wv = tid >> 6, nwv = NT >> 6, W = L.dd + L.M;
-        for (int r = wv; r < nrows; r += nwv) {
-            const float* xr = xm + (size_t)r * L.dd;
-            const float* ur = um + (size_t)r * L.M - L.dd;          // indexed by k >= dd only (um is null when M == 0)
-            float* dst = xin + r * L.ldx;
+        for (int r = wv; r < nrows; r += 2 * nwv) {
+            const int r2 = r + nwv;
+            const bool two = r2 < nrows;
+            const int rb = two ? r2 : r;
+            const float* xr[2] = {xm + (size_t)r * L.dd, xm + (size_t)rb * L.dd};
+            const float* ur[2] = {um + (size_t)r * L.M - L.dd, um + (size_t)rb * L.M - L.dd};   // indexed by k >= dd only (um is null when M == 0)
+            float* dst[2] = {xin + r * L.ldx, xin + rb * L.ldx};
+            float e0 = 0.f, e1 = 0.f;
+            if (lane < L.dl) { e0 = em[(size_t)r * L.dl + lane]; e1 = em[(size_t)rb * L.dl + lane]; }
             for (int k0 = lane; k0 < W; k0 += 256) {
-                float v[4];
+                float v[2][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = k0 + 64 * e;
-                    v[e] = k < L.dd ? xr[k] : k < W ? ur[k] : 0.f;
-                }
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int k = k0 + 64 * e;
-                    if (k < W) dst[k < L.dd ? k : L.uoff + (k - L.dd)] = v[e];
-                }
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = k0 + 64 * e;
+                        v[h][e] = k < L.dd ? xr[h][k] : k < W ? ur[h][k] : 0.f;
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = k0 + 64 * e;
+                        if (k < W && (h == 0 || two)) dst[h][k < L.dd ? k : L.uoff + (k - L.dd)] = v[h][e];
+                    }
             }
-            if (lane < L.dl) se[r * lds + lane] = em[(size_t)r * L.dl + lane];
+            if (lane < L.dl) { se[r * lds + lane] = e0; if (two) se[r2 * lds + lane] = e1; }
         }
     }
     for (int r = tid; r < TR; r += NT) {
@@ -1063,28 +1106,30 @@ __global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, 
     }
     __syncthreads();
     MSTAMP(303);
-    // ---- per-row Gaussian log-densities   (models/nets.py:306-314, 45-52): four lanes per row take every fourth
-    // feature, then two xor-shuffles add the partial sums (fixed order)
+    // ---- per-row Gaussian log-densities   (models/nets.py:306-314, 45-52): sixteen lanes per row take every sixteenth
+    // feature, then four xor-shuffles add the partial sums (fixed order)
     {
-        const int r = tid >> 2, part = tid & 3;
-        const bool live = r < nrows;                // (tid < 4 TR <= NT: whole waves take the same branch below)
+        const int r = tid >> 4, part = tid & 15;
+        const bool live = r < nrows;                // (tid < 16 TR <= NT: whole waves take the same branch below)
         const int rr = live ? r : 0;
         const float dv = C.decoder_var;
         const float logdv = logf(dv);
         float lpx = 0.f, lqc = 0.f, lp = 0.f;
-        if (tid < 4 * TR) {
-            for (int k = part; k < L.dd; k += 4) {
+        if (tid < 16 * TR) {
+            for (int k = part; k < L.dd; k += 16) {
                 const float df = xin[rr * L.ldx + k] - sf[rr * ldf + k];
                 lpx += -0.5f * (LOG2PI + logdv + df * df / dv);
             }
-            for (int k = part; k < L.dl; k += 4) {
+            for (int k = part; k < L.dl; k += 16) {
                 const float zz = sz[rr * lds + k], gg = sg[rr * lds + k], vv = sv[rr * lds + k], ll = sl[rr * lds + k];
                 const float dq = zz - gg;
                 lqc += -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
                 lp += -0.5f * (LOG2PI + logf(ll) + zz * zz / ll);
             }
-            lpx += __shfl_xor(lpx, 1); lqc += __shfl_xor(lqc, 1); lp += __shfl_xor(lp, 1);
-            lpx += __shfl_xor(lpx, 2); lqc += __shfl_xor(lqc, 2); lp += __shfl_xor(lp, 2);
+#pragma unroll
+            for (int sft = 1; sft < 16; sft <<= 1) {
+                lpx += __shfl_xor(lpx, sft); lqc += __shfl_xor(lqc, sft); lp += __shfl_xor(lp, sft);
+            }
             if (live && part == 0) {
                 wsm[L.ws.lpx + row0 + r] = lpx;
                 wsm[L.ws.lqc + row0 + r] = lqc;

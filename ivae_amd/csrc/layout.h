@@ -61,7 +61,9 @@ struct Layout {
 #ifndef IVAE_CHAIN_MIN_TILES
 #define IVAE_CHAIN_MIN_TILES 128
 #endif
-#define IVAE_CHAIN_LDS_LIMIT (96 * 1024)    // larger row-chain tiles leave the three-kernel path (one chain per workgroup)
+#ifndef IVAE_CHAIN_LDS_LIMIT
+#define IVAE_CHAIN_LDS_LIMIT (128 * 1024)
+#endif    // larger row-chain tiles leave the three-kernel path (one chain per workgroup)
 
 static inline int ivae_up16(int x) { return (x + 15) & ~15; }
 static inline int ivae_ld4o(int x) { return (((x + 3) >> 2) | 1) << 2; }     // smallest 4*odd >= x
