@@ -77,6 +77,19 @@ extern "C" int ivae_debug_set_prof_mf(void* buf) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
 
+#ifdef MF_WARM_ARGS
+__device__ __forceinline__ void warm_kernel_args() {
+    typedef const int __attribute__((address_space(4))) cint4;
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(Layout) + 63) / 64); ++i) any |= *(cint4*)(p + 64 * i);
+    asm volatile("" ::"s"(any));
+}
+#else
+__device__ __forceinline__ void warm_kernel_args() {}
+#endif
+
 __device__ __forceinline__ int up16(int x) { return (x + 15) & ~15; }
 
 // activation h = act(p) and its derivative d = act'(p) from ONE evaluation of the transcendental: the forward epilogue
@@ -667,6 +680,8 @@ __host__ __device__ __forceinline__ int wgrad_ngroups(int dout) { return ((dout 
 __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(Layout L, const float* __restrict__ x, const float* __restrict__ u,
                                               float* __restrict__ ws, float* __restrict__ slabs, long slab_stride) {
     WSTAMP(0);
+    warm_kernel_args();
+    WSTAMP(8);
     const int model = blockIdx.y, row0 = blockIdx.x * L.trw, nrows = min(L.trw, L.B - row0);
     // blockIdx.z -> (MLP, layer, k group, n group)
     int m = -1, li = 0, job = 0;
@@ -678,11 +693,13 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(Layout L, const float* 
 #pragma unroll
             for (int l = 0; l < IVAE_MAX_LAYERS; ++l) {
                 const int nj = L.wg_jobs[mi][l];
-                if (m < 0 && z < nj) { m = mm; li = l; job = z; }
+                const bool hit = z >= 0 && z < nj;          // (selects, not branches: z only decreases, one interval holds it)
+                m = hit ? mm : m; li = hit ? l : li; job = hit ? z : job;
                 z -= nj;
             }
         }
     }
+    WSTAMP(6);
     if (m < 0) return;
     const MlpDesc& D = L.mlp[m];
     const int kg = wgrad_kgroups(D.lay[li].din);
@@ -695,6 +712,10 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(Layout L, const float* 
     J.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.slab_ld;
     J.slab_bytes = L.n_params * 4; J.w_off = D.lay[li].w_off; J.b_off = D.lay[li].b_off;
     J.actT = wsm; J.act_lim = 0; J.in_a = J.in_b = wsm; J.na = J.K; J.nb = 0;
+#ifdef MF_PROF
+    asm volatile("" ::"s"(J.N), "s"(J.K), "s"(J.dlt), "s"(J.w_off), "s"(J.b_off), "s"(J.dlt_lim));
+    WSTAMP(7);
+#endif
     if (li > 0) {
         J.actT = wsm + D.lay[li - 1].pre_off + row0;
         const long lim = L.ws.per_model - (D.lay[li - 1].pre_off + row0);

@@ -40,5 +40,5 @@ for rep in range(3):
     ops.backward(shape, coef, params, x, u, eps, ws)
     torch.cuda.synchronize()
     L.ivae_debug_set_prof_mf(C.c_void_p(0))
-    b = buf.cpu().view(-1, 2)[1500:1506, 1].tolist()
-    print("k_wgrad job stamps (cycles from entry):", [t - b[0] for t in b])
+    b = buf.cpu().view(-1, 2)[1500:1509, 1].tolist()
+    print("k_wgrad job stamps (cycles from entry; 6 = decoded, 7 = job descriptor filled):", {i: t - b[0] for i, t in zip((0, 1, 2, 3, 4, 5, 6, 7, 8), b)})
