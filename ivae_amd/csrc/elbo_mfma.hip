@@ -1,25 +1,29 @@
 // Shape-generic ELBO forward / backward kernels on the fp32 matrix cores (any dims, activation, depth).
 //
-// One workgroup of NW = 4 / 8 / 16 waves owns a tile of TR = 16/32/64 batch rows of one model (k_wgrad: 16 .. 256 rows).
-// Every layer product (forward, input gradient, weight gradient) is the same "row-row" contraction
+// One workgroup of NW = 4 / 8 / 16 waves owns a tile of TR = 16/32/64 batch rows of one model.  Every layer product
+// (forward, input gradient, weight gradient) is the same "row-row" contraction
 //
 //        out[i][j] = sum_k  A[i][k] * Bm[j][k]          (v_mfma_f32_16x16x4_f32, exact fp32 FMA chain)
 //
-// with A resident in LDS (activation / delta tiles, row stride 4*odd floats so that 128-bit operand reads spread
-// over the banks) and Bm streamed through LDS in chunks of 16 NW output columns x 64 contraction steps:
 //   forward      A = layer input  [row][k]      Bm = W[n][k]  (+ bias as column K: inputs carry a constant-1 column)
 //   dgrad        A = delta        [row][n]      Bm = W^T[k][n]
 //   wgrad        A = delta^T      [n][row]      Bm = input^T[k][row]  (+ a row of ones: bias gradient)
-// A lane loads 4 consecutive k of its row as one ds_read_b128 and feeds them to 4 MFMAs; both operands use the same
-// k permutation, so sums are unchanged up to fp32 order.  The chunks are double-buffered in LDS and their global loads
-// are issued one chunk ahead into registers (also across layer boundaries), so the L2 latency of the weights hides
-// behind the previous chunk's MFMAs.  Hidden activations and their derivatives go to the caller's workspace feature-major
-// ((H, Bp), Bp = batch rounded up to 64) so that the backward pass reads them as transposed operands directly.
-// The step is split by data dependency: k_fwd_enc (three MLP chains as concurrent workgroups), k_dec (decoder forward,
-// row log-densities, decoder input-gradient chain), k_bwd_enc (head deltas + input-gradient chains), then k_wgrad --
-// nothing on the dependent chain of layers waits for a weight gradient, so every layer's is its own workgroup, fed by
-// the layer deltas the chains left in the workspace.  Weight gradients are written as per-tile slabs and summed in a
-// fixed order by k_reduce: results are bitwise reproducible run to run (no float atomics).
+// Forward / dgrad: A is resident in LDS (activation / delta tiles, row stride 4*odd floats so that 128-bit operand reads
+// spread over the banks); a wave owns a 16-column output tile for all row tiles of the workgroup and loads its Bm
+// fragments -- the weights: a few hundred KB, L2-resident -- STRAIGHT from global memory in MFMA operand layout, a whole
+// tile ahead of their use (tile_gemm).  Nothing of Bm goes through LDS and a product costs one workgroup barrier.  A lane
+// takes 4 consecutive k of its row per 128-bit load and feeds them to 4 MFMAs; both operands use the same k permutation,
+// so sums are unchanged up to fp32 order.  Hidden activations and their derivatives go to the caller's workspace
+// feature-major ((H, Bp), Bp = batch rounded up to an odd multiple of 64) so that the backward pass reads them as
+// transposed operands directly.
+// The step is split by data dependency.  Launches that fill the chip run everything that depends only on a tile's own
+// rows in ONE kernel (k_chain: encoder / prior chains as three concurrent wave groups -> z -> decoder -> log-densities ->
+// decoder backward -> [plain ELBO] encoder / prior backward); small launches and the data-parallel phases use the same
+// stages as three kernels (k_fwd_enc, k_dec, k_bwd_enc: one chain per workgroup, three times the CUs).  Nothing on the
+// dependent chain of layers waits for a weight gradient: k_wgrad forms them afterwards from the layer deltas the chains
+// left in the workspace -- no LDS, no barrier, one wave per 4 x 4 block of output tiles, both operands streamed from
+// global memory in fragment layout -- as per-tile slabs that k_reduce sums in a fixed order: results are bitwise
+// reproducible run to run (no float atomics).
 //
 // Reference arithmetic restated here: models/nets.py:114-121 (MLP.forward), 301-314 (Normal.sample / log_pdf),
 // 45-52 (log_normal), 450-475, 587-599, 165-185, 224-243 (forward / elbo of the four model classes); backward =

@@ -26,8 +26,9 @@ __device__ __forceinline__ void adam_update(float& p, float& m, float& v, float 
     m = mi;
     v = vi;
 }
-// fuse != null: also apply Adam (returns hipErrorNotSupported-free: *fused tells the caller whether it happened -- a model
-// whose gradient needs no slab reduction has no k_reduce launch to ride on).
+// fuse != null: the slab reduction also applies Adam; *fused tells the caller whether it did (a model whose gradient
+// needs no slab reduction has no k_reduce launch to ride on: the caller then launches the optimiser itself).
+// enc_bwd_done: launch_forward's row-chain kernel already ran the encoder / prior input-gradient chains.
 hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
                            const float* eps, float* loss_out, float* grads, float* ws, bool dec_bwd_done, hipStream_t st,
                            const AdamFuse* fuse = nullptr, bool* fused = nullptr, bool enc_bwd_done = false);
