@@ -116,15 +116,15 @@ __device__ __forceinline__ void act_both(float p, int act, float slope, float& h
 // Contraction indices k >= K multiply exact zeros (the last 16-wide k block is masked in registers); output columns
 // j past the real extent are computed from whatever the range-checked loads return and dropped by the epilogues.
 enum { SRC_NONE = 0, SRC_W, SRC_WT };
-struct BSrc {
+struct BSrc {                       // (kept small: it lives in scalar registers, two or three at a time)
     const float* p;
-    long d2;
-    int kind;
-    int J1, J, K;
-    int Jt, Kc;                     // extents of the product: output columns (ones row included), contraction steps (bias column included)
-    int ld, ld2;
-    int hole0, hole;
     unsigned lim;                   // floats readable from p (range of the buffer descriptor)
+    int kind;
+    int boff;                       // SRC_W: float offset of the bias from p
+    int K;                          // real contraction extent
+    int Jt, Kc;                     // extents of the product: output columns, contraction steps (bias column and hole included)
+    int ld;
+    int hole0, hole;
 };
 
 // ------------------------------------------------------------------------------ the contraction
@@ -149,7 +149,7 @@ struct Stream {           // prefetch state carried from one product to the next
 // past them read range-checked addresses and are never used): the compiler can then count outstanding loads exactly, and
 // a wait for the group that is needed now does not also wait for the groups issued after it.
 template <int KIND>
-__device__ __forceinline__ void group_load(f32x4 (&dst)[BPD], float& bias, const BSrc& S, int col0, int blk0) {
+__device__ __forceinline__ void group_load(f32x4 (&dst)[BPD], float& bias, const BSrc& S, int col0, int blk0, unsigned lim) {
     if (KIND == SRC_NONE) return;
     int lane = threadIdx.x & 63;
 #ifndef MF_TRANSPARENT
@@ -157,7 +157,7 @@ __device__ __forceinline__ void group_load(f32x4 (&dst)[BPD], float& bias, const
 #endif
     const int c = lane & 15, q = lane >> 4;
     const int j = col0 + c;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.p, 0, (int)(S.lim * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.p, 0, (int)(lim * 4u), 0x00020000);
     if (KIND == SRC_W) {
         const int rowo = j * S.ld + 4 * q;
         const int hend = S.hole0 + S.hole;
@@ -167,7 +167,7 @@ __device__ __forceinline__ void group_load(f32x4 (&dst)[BPD], float& bias, const
             const int sh = kf >= hend ? S.hole : 0;
             dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (rowo + 16 * (blk0 + u) - sh) * 4, 0, 0));
         }
-        bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ((int)S.d2 + j) * 4, 0, 0));
+        bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (S.boff + j) * 4, 0, 0));
     } else {
 #pragma unroll
         for (int u = 0; u < BPD; ++u) {
@@ -186,7 +186,7 @@ __device__ __forceinline__ void stream_begin(Stream& St, const BSrc& S, int nw =
     for (int u = 0; u < BPD; ++u) St.bq[u] = ZERO4;
 #pragma unroll
     for (int r = 0; r < MAX_RTE; ++r) St.aux[r] = ZERO4;
-    group_load<KIND>(St.bq, St.bias, S, 16 * (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) % nw), 0);
+    group_load<KIND>(St.bq, St.bias, S, 16 * (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) % nw), 0, S.lim);
 }
 // a k block that reaches past the real contraction extent: those indices become exact zeros, the bias enters
 template <int KIND>
@@ -233,13 +233,14 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) % NW, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int nblk = up16(S.Kc) >> 4, ngrp = (nblk + BPD - 1) / BPD;
     const int kmask = KIND == SRC_W ? S.Kc - 1 : S.K;     // k blocks reaching past it are masked (SRC_W: only the last one)
-    BSrc nsrc = next;
-    if (NKIND == SRC_NONE) { nsrc = S; nsrc.lim = 0; }
+    // nothing follows: the same loads from S with an empty range (every one out of range: no memory traffic, same count)
+    const BSrc& nsrc = NKIND == SRC_NONE ? S : next;
+    const unsigned nlim = NKIND == SRC_NONE ? 0u : next.lim;
     MSTAMPF(2);
     __syncthreads();                               // the A tile is complete
     MSTAMPF(3);
     if (16 * wave >= S.Jt) {                       // no tile of this product is mine
-        group_load<NK>(St.bq, St.bias, nsrc, 16 * wave, 0);
+        group_load<NK>(St.bq, St.bias, nsrc, 16 * wave, 0, nlim);
 #pragma unroll
         for (int rt = 0; rt < RTE; ++rt) St.aux[rt] = pre_next(rt, 16 * wave);
         return;
@@ -249,11 +250,11 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
         f32x4 nx[BPD], naux[RTE];
         float nbias = 0.f;
         if (col0 + NCH < S.Jt) {
-            group_load<KIND>(nx, nbias, S, col0 + NCH, 0);
+            group_load<KIND>(nx, nbias, S, col0 + NCH, 0, S.lim);
 #pragma unroll
             for (int rt = 0; rt < RTE; ++rt) naux[rt] = pre(rt, col0 + NCH);
         } else {
-            group_load<NK>(nx, nbias, nsrc, 16 * wave, 0);
+            group_load<NK>(nx, nbias, nsrc, 16 * wave, 0, nlim);
 #pragma unroll
             for (int rt = 0; rt < RTE; ++rt) naux[rt] = pre_next(rt, 16 * wave);
         }
@@ -299,7 +300,7 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const
             float nob;
 #pragma unroll
             for (int u = 0; u < BPD; ++u) cur[u] = St.bq[u];
-            group_load<KIND>(St.bq, nob, S, col0, (g + 1) * BPD);
+            group_load<KIND>(St.bq, nob, S, col0, (g + 1) * BPD, S.lim);
             group(cur, g);
         }
         {   // last group.  The epilogue's global operands are older than every load still outstanding but the next tile's:
@@ -342,10 +343,10 @@ __device__ __forceinline__ BSrc src_none() {
 // forward operand of layer li
 __device__ __forceinline__ BSrc src_w(const Layout& L, const MlpDesc& D, const float* P, int li, bool holey) {
     BSrc S = src_none();
-    S.kind = SRC_W; S.p = P + D.lay[li].w_off; S.d2 = D.lay[li].b_off - D.lay[li].w_off;
-    S.J1 = S.J = D.lay[li].dout; S.K = D.lay[li].din; S.ld = D.lay[li].din; S.lim = (unsigned)(L.n_params - D.lay[li].w_off);
+    S.kind = SRC_W; S.p = P + D.lay[li].w_off; S.boff = D.lay[li].b_off - D.lay[li].w_off;
+    S.Jt = D.lay[li].dout; S.K = D.lay[li].din; S.ld = D.lay[li].din; S.lim = (unsigned)(L.n_params - D.lay[li].w_off);
     if (holey) { S.hole0 = L.dd; S.hole = L.uoff - L.dd; }
-    S.Jt = S.J; S.Kc = S.K + S.hole + 1;
+    S.Kc = S.K + S.hole + 1;
     return S;
 }
 
@@ -481,9 +482,9 @@ struct BwdCtx {
 // Streamed operand of the input-gradient product of layer li: W^T.
 __device__ __forceinline__ BSrc dgrad_src(const BwdCtx& X, const MlpDesc& D, int li) {
     BSrc S = src_none();
-    S.kind = SRC_WT; S.p = X.P + D.lay[li].w_off; S.J1 = S.J = D.lay[li].din; S.K = D.lay[li].dout; S.ld = D.lay[li].din;
+    S.kind = SRC_WT; S.p = X.P + D.lay[li].w_off; S.Jt = D.lay[li].din; S.K = D.lay[li].dout; S.ld = D.lay[li].din;
     S.lim = (unsigned)(X.np - D.lay[li].w_off);
-    S.Jt = S.J; S.Kc = S.K;
+    S.Kc = S.K;
     return S;
 }
 // Input-gradient chain of one MLP for a row tile.  On entry X.d0 holds dLoss/d(output) (rows >= nrows zero) and the
