@@ -34,9 +34,23 @@ WIDE = {100: (10, 10, 40, 600, 3, "lrelu", 70, False, 1),      # hidden widths w
         102: (33, 12, 130, 300, 3, "sigmoid", 300, False, 2)}
 
 
-@pytest.mark.parametrize("seed", list(range(40)) + sorted(WIDE))
-def test_random_shape_matches_fp64_oracle(seed):
-    dd, dl, M, H, L, act, B, pairwise, n_models = WIDE[seed] if seed in WIDE else _case(seed)
+# launches of at least 128 row tiles: the fused row-chain kernel (k_chain) instead of the three chain kernels -- ragged
+# last tile, the two-group (no prior) form with the pairwise split, 32-row tiles, packed models, a single-layer model
+CHAIN = {200: ((10, 10, 40, 50, 3, "lrelu", 2100, False, 1), 0),
+         201: ((5, 5, 0, 100, 3, "xtanh", 2048, True, 1), 16),
+         202: ((20, 20, 200, 50, 3, "lrelu", 4103, False, 1), 32),
+         203: ((7, 3, 9, 33, 2, "sigmoid", 1030, False, 2), 0),
+         204: ((6, 4, 5, 8, 1, "none", 2100, False, 1), 0),
+         205: ((10, 10, 40, 50, 3, "lrelu", 2050, True, 1), 0)}
+
+
+@pytest.mark.parametrize("seed", list(range(40)) + sorted(WIDE) + sorted(CHAIN))
+def test_random_shape_matches_fp64_oracle(seed, monkeypatch):
+    if seed in CHAIN:
+        (dd, dl, M, H, L, act, B, pairwise, n_models), rows = CHAIN[seed]
+        monkeypatch.setitem(ops.TUNING, "tile_rows", rows)
+    else:
+        dd, dl, M, H, L, act, B, pairwise, n_models = WIDE[seed] if seed in WIDE else _case(seed)
     spec = np_ref.Spec(data_dim=dd, latent_dim=dl, aux_dim=M, hidden_dim=H, n_layers=L, activation=act, slope=.1,
                        decoder_var=.1)
     rng = np.random.RandomState(seed)
