@@ -327,13 +327,14 @@ static hipError_t launch_sliced(const PairGeom& P, const IvaeCoef& C, float logM
 // ------------------------------------------------------------------ small problems: one workgroup, one launch
 // n_rows, n_cols <= 64 and d <= 12 (every yaml config of the reference: batch 64, d = 5 or 10): the four stages above run
 // inside ONE workgroup per model, so a training step spends one launch on the pairwise terms instead of four.
-// Thread = (lane l, wave p): in the row role lane l owns row l and wave p walks columns [16p, 16p + 16); in the column
-// role lane l owns column l and wave p walks rows [16p, 16p + 16).  The four waves' partial statistics / sums meet in
-// LDS and are merged in a fixed order (deterministic), with the same arithmetic as the sliced kernels.
+// Thread = (lane l, wave p): in the row role lane l owns row l and wave p walks PSQ = 64 / NWV columns; in the column
+// role lane l owns column l and wave p walks PSQ rows.  The NWV waves' partial statistics / sums meet in LDS and are
+// merged in a fixed order (deterministic), with the same arithmetic as the sliced kernels.  The walks are serial
+// instruction streams: 16 waves (four per SIMD, 4 columns each) run them about twice as fast as 4 waves of 16 columns,
+// one per SIMD, did (a lone wave issues an instruction every ~5 cycles); d > 8 takes 8 waves (LDS for the partials).
 #define PSM 64                     // rows / columns of a small problem
-#define PSQ 16                     // per wave
-template <int DP>
-__global__ __launch_bounds__(PB) void k_pair_small(int n_rows, int n_cols, int d, IvaeCoef C, float logMN,
+template <int DP, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_pair_small(int n_rows, int n_cols, int d, IvaeCoef C, float logMN,
                                                    const float* __restrict__ z, const float* __restrict__ g,
                                                    const float* __restrict__ v, float* __restrict__ lq,
                                                    float* __restrict__ lqi, float* __restrict__ lse_s,
@@ -349,18 +350,26 @@ __global__ __launch_bounds__(PB) void k_pair_small(int n_rows, int n_cols, int d
     float* LK = Z + PSM * DP;               // (PSM, DP) lse_k (natural log)
     float* LS = LK + PSM * DP;              // (PSM) lse_s
     float* part = LS + PSM;                 // stage 1-2: pm, ps (4, DP + 1, PSM) each; stage 3-4: rz, cg, cv partials (4, DP, PSM) each
+    constexpr int PSQ = PSM / NWV, NTH = 64 * NWV;
     float* pm = part;
-    float* ps = pm + 4 * (DP + 1) * PSM;
+    float* ps = pm + NWV * (DP + 1) * PSM;
     float* pr = part;
-    float* pg = pr + 4 * DP * PSM;
-    float* pv = pg + 4 * DP * PSM;
+    float* pg = pr + NWV * DP * PSM;
+    float* pv = pg + NWV * DP * PSM;
     const int tid = threadIdx.x, l = tid & 63, p = tid >> 6;
     const float cP = C.b - C.c, cQ = C.c - C.d;
 
-    stage_cols<DP>(g, v, 0, n_cols, d, G, W2, A2);
-    for (int e = tid; e < n_rows * DP; e += PB) {
-        const int i = e / DP, k = e - i * DP;
-        Z[e] = k < d ? z[(size_t)i * d + k] : 0.f;
+    for (int e = tid; e < PSM * DP; e += NTH) {            // column constants (stage_cols' arithmetic) and rows -> LDS
+        const int j = e / DP, k = e - j * DP;
+        float gg = 0.f, w2 = 0.f, a2 = 0.f, zz = 0.f;
+        if (k < d && j < n_cols) {
+            const float vv = v[(size_t)j * d + k];
+            gg = g[(size_t)j * d + k];
+            w2 = (0.5f * LOG2E) / vv;
+            a2 = (-0.5f * LOG2E) * (LOG2PI + logf(vv));
+        }
+        if (k < d && j < n_rows) zz = z[(size_t)j * d + k];
+        G[e] = gg; W2[e] = w2; A2[e] = a2; Z[e] = zz;
     }
     __syncthreads();
 
@@ -405,15 +414,15 @@ __global__ __launch_bounds__(PB) void k_pair_small(int n_rows, int n_cols, int d
     __syncthreads();
 
     // ---- stage 2: merge the four waves (log2 units in, natural-log LSE out); plane DP is the sum-over-k statistic
-    for (int e = tid; e < (d + 1) * PSM; e += PB) {
+    for (int e = tid; e < (d + 1) * PSM; e += NTH) {
         const int kk = e / PSM, i = e - kk * PSM;
         const int k = kk == d ? DP : kk;
         float M = NEG_BIG;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) M = fmaxf(M, pm[(w * (DP + 1) + k) * PSM + i]);
+        for (int w = 0; w < NWV; ++w) M = fmaxf(M, pm[(w * (DP + 1) + k) * PSM + i]);
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) sum += ps[(w * (DP + 1) + k) * PSM + i] * exp2f(pm[(w * (DP + 1) + k) * PSM + i] - M);
+        for (int w = 0; w < NWV; ++w) sum += ps[(w * (DP + 1) + k) * PSM + i] * exp2f(pm[(w * (DP + 1) + k) * PSM + i] - M);
         const float lse = M * LN2 + logf(sum);
         if (kk == d) { LS[i] = lse; if (i < n_rows) lse_s[i] = lse; }
         else { LK[i * DP + kk] = lse; if (i < n_rows) lse_k[(size_t)i * d + kk] = lse; }
@@ -480,25 +489,43 @@ __global__ __launch_bounds__(PB) void k_pair_small(int n_rows, int n_cols, int d
     __syncthreads();
 
     // ---- stage 4: fixed-order sums of the four waves' partials
-    for (int e = tid; e < d * PSM; e += PB) {
+    for (int e = tid; e < d * PSM; e += NTH) {
         const int k = e / PSM, i = e - k * PSM;
-        if (i < n_rows) rz[(size_t)i * d + k] = ((pr[(0 * DP + k) * PSM + i] + pr[(1 * DP + k) * PSM + i]) + pr[(2 * DP + k) * PSM + i]) + pr[(3 * DP + k) * PSM + i];
-        if (i < n_cols) {
-            cg[(size_t)i * d + k] = ((pg[(0 * DP + k) * PSM + i] + pg[(1 * DP + k) * PSM + i]) + pg[(2 * DP + k) * PSM + i]) + pg[(3 * DP + k) * PSM + i];
-            cv[(size_t)i * d + k] = ((pv[(0 * DP + k) * PSM + i] + pv[(1 * DP + k) * PSM + i]) + pv[(2 * DP + k) * PSM + i]) + pv[(3 * DP + k) * PSM + i];
+        float ar = 0.f, ag = 0.f, av = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            ar += pr[(w * DP + k) * PSM + i];
+            ag += pg[(w * DP + k) * PSM + i];
+            av += pv[(w * DP + k) * PSM + i];
         }
+        if (i < n_rows) rz[(size_t)i * d + k] = ar;
+        if (i < n_cols) { cg[(size_t)i * d + k] = ag; cv[(size_t)i * d + k] = av; }
     }
 }
 
+template <int DP, int NWV>
+static hipError_t launch_small_w(int n_rows, int n_cols, int d, const IvaeCoef& C, float logMN, const float* z, const float* g,
+                                 const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz, float* cg,
+                                 float* cv, int n_models, size_t mstride, hipStream_t st) {
+    const int np = 2 * NWV * (DP + 1) > 3 * NWV * DP ? 2 * NWV * (DP + 1) : 3 * NWV * DP;
+    const size_t bytes = (size_t)(5 * PSM * DP + PSM + np * PSM) * sizeof(float);      // 109 KB at DP = 8 with 16 waves, 90 KB at DP = 12 with 8
+    static SmemCache cur = {};
+    hipError_t e = set_smem((const void*)k_pair_small<DP, NWV>, (int)bytes, cur);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_pair_small<DP, NWV>), dim3(n_models), dim3(64 * NWV), bytes, st, n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi,
+                       lse_s, lse_k, rz, cg, cv, mstride);
+    return hipGetLastError();
+}
+// a few models: as many waves as the LDS allows (the walks are latency-bound); a chip-filling pack: four waves per model,
+// several models per CU
 template <int DP>
 static hipError_t launch_small(int n_rows, int n_cols, int d, const IvaeCoef& C, float logMN, const float* z, const float* g,
                                const float* v, float* lq, float* lqi, float* lse_s, float* lse_k, float* rz, float* cg,
                                float* cv, int n_models, size_t mstride, hipStream_t st) {
-    const int np = 2 * 4 * (DP + 1) > 3 * 4 * DP ? 2 * 4 * (DP + 1) : 3 * 4 * DP;
-    const size_t bytes = (size_t)(5 * PSM * DP + PSM + np * PSM) * sizeof(float);      // <= 53 KB at DP = 12
-    hipLaunchKernelGGL(k_pair_small<DP>, dim3(n_models), dim3(PB), bytes, st, n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi,
-                       lse_s, lse_k, rz, cg, cv, mstride);
-    return hipGetLastError();
+    if (n_models >= 128)
+        return launch_small_w<DP, 4>(n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, n_models, mstride, st);
+    return launch_small_w<DP, (DP <= 8 ? 16 : 8)>(n_rows, n_cols, d, C, logMN, z, g, v, lq, lqi, lse_s, lse_k, rz, cg, cv, n_models,
+                                                  mstride, st);
 }
 
 // ------------------------------------------------------------------ 32 < d <= 64: one wavefront per row / column

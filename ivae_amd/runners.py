@@ -177,8 +177,10 @@ def runner(args, config, *, replay=None, trace=None):
         losses, _ = pack.epoch(Xe, Ue, a, b, c, d, N, eps=eps, z_out=Ze)              # (nb, K)
         # the per-step batch scores (runners/ivae.py:86) of all seeds, one launch per epoch
         cc = ops.corr_batched(Se.reshape(nb * K, B, d_latent), Ze.view(nb * K, B, d_latent))
-        train_loss = (losses.sum(0) / nb).cpu().numpy()                               # the epoch's one sync
-        scores = np.array(_assignment_scores(cc.abs().cpu().numpy())).reshape(nb, K).mean(0)
+        # the epoch's one sync; summed as the reference does (`train_loss += loss.item()`, runners/ivae.py:84,112: float64,
+        # step by step), which also makes a seed's figure independent of how many seeds are packed beside it
+        train_loss = losses.cpu().numpy().astype(np.float64).sum(0) / nb
+        scores = np.array(_assignment_scores(cc.abs().cpu().numpy()), dtype=np.float64).reshape(nb, K).sum(0) / nb
         for i in range(K):
             loss_hists[i].append(float(train_loss[i]))
             perf_hists[i].append(float(scores[i]))
