@@ -73,7 +73,20 @@ def test_two_epochs_match_reference_trace(dataset):
         mcc_sample = ivae_amd.mean_corr_coef(torch.from_numpy(S).to(dev), z)
         d_mean.append(mcc_mean - float(g[f"mcc_mean{seed}"]))
         d_sample.append(mcc_sample - float(g[f"mcc_sample{seed}"]))
-    # 1250 chaotic SGD steps amplify fp32 round-off: single seeds may drift a little, the seed average (the
-    # quantity the paper reports, and north_star's "+-0.01 over fixed seeds") must not.
-    assert max(map(abs, d_mean)) < 0.03 and max(map(abs, d_sample)) < 0.03, (d_mean, d_sample)
+        # Per seed: inside the envelope of the REFERENCE's own twins -- the same run with its initial parameters moved by
+        # 1e-6 relative (tools/make_golden.py::make_trace_twins).  1250 Adam steps at lr 1e-2 amplify fp32 round-off: the
+        # reference's final MCC moves by up to 0.017 between twins of one seed, so no implementation that is not
+        # bit-identical to torch can meet +-0.01 per seed; the envelope, widened by its own range + 0.005, is the bound.
+        for got, key in ((mcc_mean, "mcc_mean"), (mcc_sample, "mcc_sample")):
+            ens = np.concatenate([g[f"sens_{key}{seed}"], [float(g[f"{key}{seed}"])]])
+            pad = (ens.max() - ens.min()) + 0.005
+            assert ens.min() - pad <= got <= ens.max() + pad, (seed, key, got, ens.tolist())
+        # ... and so do the late losses (window means of the twins bracket ours)
+        tw = g[f"sens_loss{seed}"]
+        for lo in range(steps - 250, steps, 125):
+            ens = np.concatenate([tw[:, lo:lo + 125].mean(1), [ref[lo:lo + 125].mean()]])
+            pad = (ens.max() - ens.min()) + 0.02 * abs(ens.mean())
+            assert ens.min() - pad <= loss[seed, lo:lo + 125].mean() <= ens.max() + pad, (seed, lo, ens.tolist())
+    # The seed average (the quantity the paper reports, and north_star's "+-0.01 over fixed seeds") against the average
+    # over the reference's runs.
     assert abs(np.mean(d_mean)) < 0.01 and abs(np.mean(d_sample)) < 0.01, (d_mean, d_sample)

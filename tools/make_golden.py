@@ -246,6 +246,58 @@ def make_traces(n_seeds=4, epochs=2, B=64):
     np.savez_compressed(os.path.join(OUT, "trace_cfg2.npz"), **out)
 
 
+def make_trace_twins(n_twins=4):
+    """Sensitivity of the REFERENCE trajectory of make_traces: the same runs with the initial parameters moved by ~1e-6
+    relative (a few fp32 roundings; same batches, same noise).  1250 Adam steps at lr 1e-2 amplify that; the spread of
+    the twins' final MCC and late losses is what tests/test_gpu_e2e.py holds ivae_amd to, instead of a guessed tolerance.
+    Adds sens_* arrays to tests/golden/trace_cfg2.npz after checking that the stored baseline reproduces bit for bit."""
+    if not hasattr(np, "int"):
+        np.int = int
+    from data.data import generate_data
+    path = os.path.join(OUT, "trace_cfg2.npz")
+    old = dict(np.load(path))
+    n_seeds, epochs, B = int(old["n_seeds"]), int(old["epochs"]), int(old["batch"])
+    S, X, U, _, _ = generate_data(1000, 40, 10, 10, n_layers=3, seed=1, prior='gauss', activation='lrelu',
+                                  batch_size=0, repeat_linearity=True)
+    Xt, Ut = torch.from_numpy(X), torch.from_numpy(U)
+    N = X.shape[0]
+
+    def run(seed, perturb):
+        torch.manual_seed(seed)
+        model = iVAE(10, 10, 40, n_layers=3, hidden_dim=50, activation='lrelu', slope=.1)
+        if perturb:
+            gen = torch.Generator().manual_seed(4242 + perturb)
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.mul_(1 + 1e-6 * torch.randn(p.shape, generator=gen))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        losses, step = [], 0
+        for epoch in range(epochs):
+            for idx in trace_batches(seed, epoch, N, B):
+                torch.manual_seed(1_000_000 * (seed + 1) + step)
+                opt.zero_grad()
+                elbo, z = model.elbo(Xt[idx], Ut[idx])
+                elbo.mul(-1).backward()
+                opt.step()
+                losses.append(-elbo.item())
+                step += 1
+        with torch.no_grad():
+            torch.manual_seed(777 + seed)
+            (_, _), (g, v), z, _ = model(Xt, Ut)
+        return np.array(losses, np.float32), float(mean_corr_coef_np(S, z.numpy())), float(mean_corr_coef_np(S, g.numpy()))
+
+    for seed in range(n_seeds):
+        base = run(seed, 0)
+        assert np.array_equal(base[0], old[f"loss{seed}"]) and base[1] == float(old[f"mcc_sample{seed}"]), "baseline does not reproduce"
+        tw = [run(seed, k) for k in range(1, n_twins + 1)]
+        old[f"sens_loss{seed}"] = np.stack([t[0] for t in tw])
+        old[f"sens_mcc_sample{seed}"] = np.array([t[1] for t in tw])
+        old[f"sens_mcc_mean{seed}"] = np.array([t[2] for t in tw])
+        print(f"twins seed {seed}: mcc_sample {base[1]:.4f} twins {old[f'sens_mcc_sample{seed}'].round(4).tolist()}  "
+              f"mcc_mean {base[2]:.4f} twins {old[f'sens_mcc_mean{seed}'].round(4).tolist()}")
+    np.savez_compressed(path, **old)
+
+
 # ---- family-A loop traces: the reference's own runners/ivae.py::runner, run unmodified ------------------------------
 RUNNER_CASES = [
     # name, yaml file of the reference, config overrides, seeds, epochs
@@ -381,6 +433,8 @@ def main():
         return make_datasets()
     if len(sys.argv) > 1 and sys.argv[1] == "traces":
         return make_traces()
+    if len(sys.argv) > 1 and sys.argv[1] == "trace_twins":
+        return make_trace_twins()
     # family B (models/nets.py:391-486, 548-599)
     make_case("ivae_plain_tiny", "iVAE", (3, 3, 4), B=5, H=8)
     make_case("ivae_plain_cfg2", "iVAE", (10, 10, 40), B=64, H=50)
