@@ -1,39 +1,32 @@
-import os, sys, time
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
-import torch, ctypes as C
-from ivae_amd import ops, _lib
-from time_generic import CFG
+#!/usr/bin/env python3
+"""Host cost of one FusedPackedTrainer.run(20) (what the driver's 20-step timed region is): enqueue time per call,
+wall time with the device, and where the Python time goes."""
+import sys, time, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from ivae_amd import ops
+from ivae_amd.trainer import FusedPackedTrainer
 dev = torch.device("cuda:0")
-shape, B, ck, N = CFG["cfg1g"]
+shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
+M = 256
+tr = FusedPackedTrainer(shape, M, 64, device=dev)
 g = torch.Generator(device=dev).manual_seed(0)
-P = shape.n_params()
-params = (torch.rand(P, generator=g, device=dev) - .5) * .2
-m = torch.zeros_like(params); v = torch.zeros_like(params)
-x = torch.randn(B, shape.data_dim, generator=g, device=dev)
-u = torch.zeros(B, shape.aux_dim, device=dev); u[:, 0] = 1
-eps = torch.randn(B, shape.latent_dim, generator=g, device=dev)
-coef = ops.make_coef(N=N, global_batch=B, **ck)
-ws = ops.Workspace()
-def t(fn, n=300):
-    for _ in range(20): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): fn()
-    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    return 1e6 * (t1 - t0) / n, 1e6 * (t2 - t0) / n
-print("elbo_fwd_bwd host/total us:", t(lambda: ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws)))
-loss, z, grads = ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws)
-print("adam host/total us:", t(lambda: ops.adam_step(params, m, v, grads, 1e-3, 1)))
-print("torch.empty x3:", t(lambda: (torch.empty(B, 10, device=dev), torch.empty(1, device=dev), torch.empty_like(params))))
-dims = shape.dims(B, 1)
-buf = ws.get(dims, dev, False)
-L = _lib.lib()
-zz = torch.empty(B, 10, device=dev); ll = torch.empty(1, device=dev); gg = torch.empty_like(params)
-st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-def raw():
-    L.ivae_elbo_fwd_bwd(C.byref(dims), C.byref(coef), C.c_void_p(params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(eps.data_ptr()), C.c_void_p(zz.data_ptr()), C.c_void_p(ll.data_ptr()), C.c_void_p(gg.data_ptr()), C.c_void_p(buf.data_ptr()), buf.numel() * 4, st)
-print("raw ctypes ivae_elbo_fwd_bwd:", t(raw))
-print("ws.get:", t(lambda: ws.get(dims, dev, False)))
-def ctx():
-    with torch.cuda.device(dev): pass
-print("cuda.device ctx:", t(ctx))
-print("_stream:", t(lambda: torch.cuda.current_stream(dev).cuda_stream))
+x = torch.randn(M, 40000, 10, generator=g, device=dev)
+u = torch.zeros(M, 40000, 40, device=dev); u[:, torch.arange(40000), torch.arange(40000) % 40] = 1
+tr.set_data(x, u)
+tr.run(40); torch.cuda.synchronize()
+for timed in (False, True):
+    t0 = time.perf_counter()
+    for _ in range(20): tr.run(20, timed=timed)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"timed={timed}: host enqueue {1e6*(t1-t0)/20:.1f} us per run(20); with device {1e6*(t2-t0)/20:.1f} us")
+# one launch, sync each time (what the driver's 20-step region is)
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); tr.run(20, timed=True); torch.cuda.synchronize(); print(f"single run(20)+sync: {1e6*(time.perf_counter()-t0):.1f} us")
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(50): tr.run(20, timed=True)
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
