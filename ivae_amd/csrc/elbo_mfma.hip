@@ -130,63 +130,43 @@ struct BSrc {                       // (kept small: it lives in scalar registers
 // ------------------------------------------------------------------------------ the contraction
 // A wave owns the 16-column tile col0 = 16 wave (+ 16 NW per pass) of a product for all RTE row tiles of the workgroup
 // and fetches its Bm fragments STRAIGHT from global memory / L2 into MFMA operand layout -- lane (c, q) holds
-// Bm[col0 + c][16 blk + 4q .. + 3], one 128-bit load per 16 contraction steps for the k-contiguous kinds, four 32-bit
-// loads for the transposing ones -- BPD blocks (one "group") ahead of their use, across pass and product boundaries too.
-// Nothing of the streamed operand goes through LDS and no barrier separates the k blocks: a product costs ONE workgroup
-// barrier (its A tile, written by the previous epilogue, must be complete).
-#define BPD 4
+// Bm[col0 + c][16 blk + 4q .. + 3], one 128-bit load per 16 contraction steps for the k-contiguous kind, four 32-bit
+// loads for the transposing one -- one block ahead of its use inside a tile.  Nothing of the streamed operand goes through
+// LDS and no barrier separates the k blocks: a product costs ONE workgroup barrier (its A tile, written by the previous
+// epilogue, must be complete).
+// What was measured on MI355X and is NOT here any more: fragments prefetched across tile and product boundaries, in groups
+// of 2 / 4 / 8 blocks.  Every deeper variant was slower (configs[3]: 59 us with this loop, 61 / 61 / 66 / 101 us with
+// groups of 1 / 2 / 4 / 8 blocks carried from product to product; batch 32768: 242 against 252 ... 523 us): the weights
+// come from L2 quickly, and the registers and loads of blocks that do not exist cost more than the latency they hid.
 #define ONES4 ((f32x4){1.f, 1.f, 1.f, 1.f})
-#define MAX_RTE 4
-struct Stream {           // prefetch state carried from one product to the next
-    f32x4 bq[BPD];        // group 0 of this wave's first tile of the upcoming product
-    float bias;           //   (+ its bias entry, SRC_W)
-    f32x4 aux[MAX_RTE];   //   (+ the global operands of its epilogue, see tile_gemm's pre / pre_next)
-    int n;                // diagnostic build: stamps written so far
+struct Stream {           // (diagnostic build: stamps written so far)
+    int n;
 };
 
-// Issue the loads of blocks blk0 .. blk0 + BPD - 1 of tile col0 of S into dst (+ the tile's bias entry, SRC_W).  KIND is
-// a compile-time copy of S.kind and every call issues the same number of loads whatever the extents are (blocks / tiles
-// past them read range-checked addresses and are never used): the compiler can then count outstanding loads exactly, and
-// a wait for the group that is needed now does not also wait for the groups issued after it.
+// Issue the loads of block blk of tile col0 of S (+ the tile's bias entry, SRC_W).  KIND is a compile-time copy of S.kind
+// and every call issues the same number of loads whatever the extents are (a block past them reads range-checked
+// addresses and is never used): the compiler can then count outstanding loads exactly, and a wait for the block that is
+// needed now does not also wait for the one issued after it.
 template <int KIND>
-__device__ __forceinline__ void group_load(f32x4 (&dst)[BPD], float& bias, const BSrc& S, int col0, int blk0, unsigned lim) {
-    if (KIND == SRC_NONE) return;
+__device__ __forceinline__ void frag_load(f32x4& dst, float& bias, const BSrc& S, int col0, int blk) {
     int lane = threadIdx.x & 63;
 #ifndef MF_TRANSPARENT
     asm volatile("" : "+v"(lane));      // opaque: keeps the per-lane addresses of every call site from being hoisted
 #endif
     const int c = lane & 15, q = lane >> 4;
     const int j = col0 + c;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.p, 0, (int)(lim * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S.p, 0, (int)(S.lim * 4u), 0x00020000);
     if (KIND == SRC_W) {
-        const int rowo = j * S.ld + 4 * q;
-        const int hend = S.hole0 + S.hole;
-#pragma unroll
-        for (int u = 0; u < BPD; ++u) {
-            const int kf = 16 * (blk0 + u) + 4 * q;
-            const int sh = kf >= hend ? S.hole : 0;
-            dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (rowo + 16 * (blk0 + u) - sh) * 4, 0, 0));
-        }
+        const int kf = 16 * blk + 4 * q;
+        const int sh = kf >= S.hole0 + S.hole ? S.hole : 0;
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (j * S.ld + kf - sh) * 4, 0, 0));
         bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (S.boff + j) * 4, 0, 0));
     } else {
+        const int vo = ((16 * blk + 4 * q) * S.ld + j) * 4;
 #pragma unroll
-        for (int u = 0; u < BPD; ++u) {
-            const int vo = ((16 * (blk0 + u) + 4 * q) * S.ld + j) * 4;
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-                dst[u][x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, x * S.ld * 4, 0));
-        }
+        for (int x = 0; x < 4; ++x)
+            dst[x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, x * S.ld * 4, 0));
     }
-}
-// first prefetch of a kernel: group 0 of this wave's first tile of product S (nw: waves of a chain's group, k_chain)
-template <int KIND>
-__device__ __forceinline__ void stream_begin(Stream& St, const BSrc& S, int nw = 1 << 20) {
-    St.bias = 0.f;
-#pragma unroll
-    for (int u = 0; u < BPD; ++u) St.bq[u] = ZERO4;
-#pragma unroll
-    for (int r = 0; r < MAX_RTE; ++r) St.aux[r] = ZERO4;
-    group_load<KIND>(St.bq, St.bias, S, 16 * (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) % nw), 0, S.lim);
 }
 // a k block that reaches past the real contraction extent: those indices become exact zeros, the bias enters
 template <int KIND>
@@ -205,124 +185,55 @@ __device__ __forceinline__ f32x4 frag_last(const BSrc& S, f32x4 b, int kf, float
     return b;
 }
 
-// out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RT (RT <= RTE row tiles), j < S.Jt, k < S.Kc; A in LDS (row stride lda).
-// KIND = S.kind, NKIND = next.kind (compile-time copies).  On entry St holds group 0 of this wave's first tile of S; on
-// exit that of `next`, whose loads are issued when this product's last pass STARTS -- a whole product ahead of their use.
+// out[i][j] = sum_k A[i][k] * Bm[j][k] for i < 16*RTE, j < S.Jt, k < S.Kc; A in LDS (row stride lda).  KIND = S.kind
+// (compile-time copy).
 // epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0): global operands
-// of the epilogue (activation derivatives of the dgrad mask), fetched a whole TILE ahead like the fragments -- a pass
-// loads pre(rt, col0 + 16 NW) for the next one, the last pass pre_next(rt, first tile) for the following product; the
-// first product of a chain finds its own in St.aux (aux_begin).  pre and pre_next issue the same number of loads.
+// of the epilogue (activation derivatives of the dgrad mask), fetched BEFORE the contraction so that they arrive under it.
 struct NoPre { __device__ __forceinline__ f32x4 operator()(int, int) const { return ZERO4; } };
-template <int RTE, class PRE>
-__device__ __forceinline__ void aux_begin(Stream& St, int nw, PRE&& pre) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) % nw;
-#pragma unroll
-    for (int rt = 0; rt < RTE; ++rt) St.aux[rt] = pre(rt, 16 * wave);
-}
-template <int RTE, int NW, int KIND, int NKIND, class EPI, class PRE = NoPre, class PREN = NoPre>
-__device__ __forceinline__ void tile_gemm(const float* A, int lda, int RT, const BSrc& S, const BSrc& next,
-                                          Stream& St, EPI&& epi, PRE&& pre = PRE(), PREN&& pre_next = PREN()) {
+template <int RTE, int NW, int KIND, class EPI, class PRE = NoPre>
+__device__ __forceinline__ void tile_gemm(const float* A, int lda, const BSrc& S, Stream& St, EPI&& epi, PRE&& pre = PRE()) {
     GEOM(NW);
     constexpr int NA = RTE == 1 ? 2 : 1;          // one row tile: two accumulators break the dependent MFMA chain
-    constexpr int NK = NKIND == SRC_NONE ? KIND : NKIND;      // nothing follows: the same number of (out-of-range) loads
     int tid = threadIdx.x;
 #ifndef MF_TRANSPARENT
     asm volatile("" : "+v"(tid));
 #endif
     // (k_chain runs several chains as groups of NW waves in one workgroup: the tile map is relative to the group)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) % NW, lane = tid & 63, c = lane & 15, q = lane >> 4;
-    const int nblk = up16(S.Kc) >> 4, ngrp = (nblk + BPD - 1) / BPD;
+    const int nblk = up16(S.Kc) >> 4;
     const int kmask = KIND == SRC_W ? S.Kc - 1 : S.K;     // k blocks reaching past it are masked (SRC_W: only the last one)
-    // nothing follows: the same loads from S with an empty range (every one out of range: no memory traffic, same count)
-    const BSrc& nsrc = NKIND == SRC_NONE ? S : next;
-    const unsigned nlim = NKIND == SRC_NONE ? 0u : next.lim;
     MSTAMPF(2);
     __syncthreads();                               // the A tile is complete
     MSTAMPF(3);
-    if (16 * wave >= S.Jt) {                       // no tile of this product is mine
-        group_load<NK>(St.bq, St.bias, nsrc, 16 * wave, 0, nlim);
-#pragma unroll
-        for (int rt = 0; rt < RTE; ++rt) St.aux[rt] = pre_next(rt, 16 * wave);
-        return;
-    }
     for (int col0 = 16 * wave; col0 < S.Jt; col0 += NCH) {
-        // my tile of the next pass, else of the following product: in flight under this whole tile
-        f32x4 nx[BPD], naux[RTE];
-        float nbias = 0.f;
-        if (col0 + NCH < S.Jt) {
-            group_load<KIND>(nx, nbias, S, col0 + NCH, 0, S.lim);
-#pragma unroll
-            for (int rt = 0; rt < RTE; ++rt) naux[rt] = pre(rt, col0 + NCH);
-        } else {
-            group_load<NK>(nx, nbias, nsrc, 16 * wave, 0, nlim);
-#pragma unroll
-            for (int rt = 0; rt < RTE; ++rt) naux[rt] = pre_next(rt, 16 * wave);
-        }
-        f32x4 acc[RTE][NA], aux[RTE];
+        f32x4 acc[RTE][NA], aux[RTE], bq;
+        float bias = 0.f;
+        frag_load<KIND>(bq, bias, S, col0, 0);
 #pragma unroll
         for (int rt = 0; rt < RTE; ++rt) {
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[rt][a] = ZERO4;
-            aux[rt] = St.aux[rt];
+            aux[rt] = pre(rt, col0);
         }
-        const float bias = St.bias;
         const float* ap = A + c * lda + 4 * q;
-        // one group of k blocks from the fragments in cur; the A fragments of the whole group are read first (rows past
-        // the operand's width are finite LDS contents that meet exact zeros)
-        auto group = [&](const f32x4 (&cur)[BPD], int g) {
-            constexpr bool AHEAD = RTE == 1;       // (more row tiles: the fragments of a whole group would spill)
-            f32x4 a[BPD][RTE];
-            if (AHEAD) {
-#pragma unroll
-                for (int u = 0; u < BPD; ++u)
-#pragma unroll
-                    for (int rt = 0; rt < RTE; ++rt) a[u][rt] = *reinterpret_cast<const f32x4*>(ap + 16 * rt * lda + 16 * (g * BPD + u));
-            }
-#pragma unroll
-            for (int u = 0; u < BPD; ++u) {
-                const int blk = g * BPD + u;
-                if (blk < nblk) {
-                    f32x4 b = cur[u];
-                    if (16 * blk + 16 > kmask) b = frag_last<KIND>(S, b, 16 * blk + 4 * q, bias);
-#pragma unroll
-                    for (int rt = 0; rt < RTE; ++rt)
-                        if (rt < RT) {
-                            const f32x4 av = AHEAD ? a[u][rt] : *reinterpret_cast<const f32x4*>(ap + 16 * rt * lda + 16 * blk);
-#pragma unroll
-                            for (int x = 0; x < 4; ++x)
-                                acc[rt][x % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[x], b[x], acc[rt][x % NA], 0, 0, 0);
-                        }
-                }
-            }
-        };
-        for (int g = 0; g + 1 < ngrp; ++g) {       // steady state: the next group of this tile is in flight under this one
-            f32x4 cur[BPD];
+        for (int blk = 0; blk < nblk; ++blk) {
+            f32x4 b = bq;
             float nob;
+            frag_load<KIND>(bq, nob, S, col0, blk + 1);          // (the block past the last one: range-checked, unused)
+            f32x4 a[RTE];
 #pragma unroll
-            for (int u = 0; u < BPD; ++u) cur[u] = St.bq[u];
-            group_load<KIND>(St.bq, nob, S, col0, (g + 1) * BPD, S.lim);
-            group(cur, g);
-        }
-        {   // last group.  The epilogue's global operands are older than every load still outstanding but the next tile's:
-            // waiting for them HERE is cheap, in the epilogue the compiler could not tell.
+            for (int rt = 0; rt < RTE; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(ap + 16 * rt * lda + 16 * blk);
+            if (16 * blk + 16 > kmask) b = frag_last<KIND>(S, b, 16 * blk + 4 * q, bias);
 #pragma unroll
-            for (int rt = 0; rt < RTE; ++rt) asm volatile("" ::"v"(aux[rt]));
-            MSTAMPF(31);
-            f32x4 cur[BPD];
+            for (int rt = 0; rt < RTE; ++rt)
 #pragma unroll
-            for (int u = 0; u < BPD; ++u) cur[u] = St.bq[u];
-            group(cur, ngrp - 1);
+                for (int x = 0; x < 4; ++x)
+                    acc[rt][x % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][x], b[x], acc[rt][x % NA], 0, 0, 0);
         }
         MSTAMPF(5);
 #pragma unroll
-        for (int rt = 0; rt < RTE; ++rt)
-            if (rt < RT) epi(rt, col0, NA == 2 ? acc[rt][0] + acc[rt][NA - 1] : acc[rt][0], aux[rt]);
+        for (int rt = 0; rt < RTE; ++rt) epi(rt, col0, NA == 2 ? acc[rt][0] + acc[rt][NA - 1] : acc[rt][0], aux[rt]);
         MSTAMPF(6);
-#pragma unroll
-        for (int u = 0; u < BPD; ++u) St.bq[u] = nx[u];
-        St.bias = nbias;
-#pragma unroll
-        for (int rt = 0; rt < RTE; ++rt) St.aux[rt] = naux[rt];
     }
 }
 
@@ -352,27 +263,25 @@ __device__ __forceinline__ BSrc src_w(const Layout& L, const MlpDesc& D, const f
 
 // One MLP forward.  `in` (LDS, stride ld_in) holds the layer-0 input with a constant-1 column after its Kin0
 // columns; `holey`: the input tile is [x | pad | u | 1] and W's columns skip the pad.  head(rt, col0, acc) receives
-// the output layer's tiles.  `next`: first streamed operand of whatever product follows this MLP.
-template <int RTE, int NW, int NEXTK, class HEAD>
-__device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const MlpDesc& D, const float* in, int ld_in, int Kin0, bool holey,
-                                        const BSrc& next, Stream& St, HEAD&& head) {
+// the output layer's tiles.
+template <int RTE, int NW, class HEAD>
+__device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const MlpDesc& D, const float* in, int ld_in, bool holey,
+                                        Stream& St, HEAD&& head) {
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const float* cur = in;
     int ldc = ld_in;
     for (int li = 0; li < L.L; ++li) {
         const bool last = li == L.L - 1;
         const BSrc S = src_w(L, D, X.P, li, holey && li == 0);
-        BSrc nx = next;
-        if (!last) nx = src_w(L, D, X.P, li + 1, false);
         MSTAMP(7);
         const int N = D.lay[li].dout;
         if (last) {
-            tile_gemm<RTE, NW, SRC_W, NEXTK>(cur, ldc, RTE, S, nx, St, head);
+            tile_gemm<RTE, NW, SRC_W>(cur, ldc, S, St, head);
         } else {
             float* dst = (li & 1) ? X.h1 : X.h0;
             float* actT = X.wsm + D.lay[li].pre_off + X.row0;
             float* derT = X.wsm + D.lay[li].der_off + X.row0;
-            tile_gemm<RTE, NW, SRC_W, SRC_W>(cur, ldc, RTE, S, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+            tile_gemm<RTE, NW, SRC_W>(cur, ldc, S, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                 const int n = col0 + c;
                 if (n < N) {
                     const int r0 = 16 * rt + 4 * q;
@@ -418,7 +327,6 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
 
     Stream St;
     St.n = 0;
-    stream_begin<SRC_W>(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0));
     MSTAMP(100);
 
     for (int i = 4 * tid; i < L.smem_enc / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(xin + i) = ZERO4;
@@ -454,7 +362,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_enc(Layout L, const float* __re
     FwdCtx X;
     X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = h0; X.h1 = h1;
     float* out = wsm + (m == IVAE_MLP_G ? L.ws.g : m == IVAE_MLP_LOGV ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
-    mlp_fwd<RTE, NW, SRC_NONE>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, src_none(), St,
+    mlp_fwd<RTE, NW>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc && L.M > 0, St,
                  [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                      const int n = col0 + c;
                      if (n < L.dl) {
@@ -508,20 +416,16 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
         const int l = max(li, 1);
         return DerLoad{X.wsm + D.lay[l - 1].der_off + X.row0, D.lay[l].din, L.Bp, c, q};
     };
-    if (L.L > 1) aux_begin<RTE>(St, NW, der_of(L.L - 1));
     for (int t = 0; t < n_prod; ++t) {
         const int li = L.L - 1 - t;
         const int K = D.lay[li].din;
         const BSrc S = dgrad_src(X, D, li);
-        BSrc nx = src_none();
-        if (t + 1 < n_prod) nx = dgrad_src(X, D, li - 1);
         MSTAMP(7);
         // dX[r][k] = sum_n delta[r][n] * W[n][k]  (times act'(pre) for a hidden input)
         const float* dcur = cur ? X.d1 : X.d0;
         if (li > 0) {
             float* dnx = cur ? X.d0 : X.d1;
             float* dltT = X.wsm + D.lay[li - 1].dlt_off + X.row0;
-            const bool more = t + 1 < n_prod;
             auto epi = [&](int rt, int col0, const f32x4& acc, const f32x4& pre) {
                 const int k = col0 + c;
                 if (k < K) {
@@ -535,12 +439,10 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
                     *reinterpret_cast<f32x4*>(dltT + (size_t)k * L.Bp + r0) = o;
                 }
             };
-            const DerLoad pre = der_of(li), pre_next = der_of(li - 1);
-            if (more) tile_gemm<RTE, NW, SRC_WT, SRC_WT>(dcur, L.ldd, RTE, S, nx, St, epi, pre, pre_next);
-            else tile_gemm<RTE, NW, SRC_WT, SRC_NONE>(dcur, L.ldd, RTE, S, nx, St, epi, pre, pre_next);
+            tile_gemm<RTE, NW, SRC_WT>(dcur, L.ldd, S, St, epi, der_of(li));
             cur ^= 1;
         } else {
-            tile_gemm<RTE, NW, SRC_WT, SRC_NONE>(dcur, L.ldd, RTE, S, nx, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
+            tile_gemm<RTE, NW, SRC_WT>(dcur, L.ldd, S, St, [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                 const int k = col0 + c;
                 if (k < K) {
 #pragma unroll
@@ -766,12 +668,9 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
     BwdCtx B;
     B.P = P; B.wsm = wsm; B.slab = nullptr;
     B.row0 = row0; B.nrows = nrows; B.TR = TR; B.np = L.n_params; B.d0 = t0; B.d1 = t1;
-    const BSrc bwd_first = dgrad_src(B, DF, L.L - 1);
 
     Stream St;
     St.n = 0;
-    if (mode & 1) stream_begin<SRC_W>(St, src_w(L, DF, P, 0, false));
-    else stream_begin<SRC_WT>(St, bwd_first);
     MSTAMP(199);
     for (int i = 4 * tid; i < L.smem_dec / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(t0 + i) = ZERO4;
     __syncthreads();
@@ -806,8 +705,7 @@ __global__ __launch_bounds__(64 * NW) void k_dec(Layout L, IvaeCoef C, int mode,
                 }
             }
         };
-        if (mode & 2) mlp_fwd<RTE, NW, SRC_WT>(L, X, DF, sz, lds, L.dl, false, bwd_first, St, head);
-        else mlp_fwd<RTE, NW, SRC_NONE>(L, X, DF, sz, lds, L.dl, false, src_none(), St, head);
+        mlp_fwd<RTE, NW>(L, X, DF, sz, lds, false, St, head);
         __syncthreads();
         // per-row Gaussian log-densities   (models/nets.py:306-314, 45-52): four lanes per row take every fourth
         // feature, then two xor-shuffles add the partial sums (fixed order)
@@ -915,8 +813,6 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
 
     Stream St;
     St.n = 0;
-    if (L.L > 1) stream_begin<SRC_WT>(St, dgrad_src(X, L.mlp[m], L.L - 1));
-    else stream_begin<SRC_NONE>(St, src_none());
     St.n = 1000;                                  // (diagnostic stamps of this kernel go to slots 1000..)
     for (int i = 4 * tid; i < L.smem_benc / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(dA + i) = ZERO4;
     __syncthreads();
@@ -1018,12 +914,9 @@ __global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, 
     const int Kx = L.uoff + L.M;
     const bool enc = m != IVAE_MLP_LOGL;
     const MlpDesc& DF = L.mlp[IVAE_MLP_F];
-    BSrc idle = src_none();                 // what the groups without a product "prefetch": nothing (every load out of range)
-    idle.p = P; idle.lim = 0;
 
     Stream St;
     St.n = 0;
-    stream_begin<SRC_W>(St, src_w(L, L.mlp[m], P, 0, enc && L.M > 0), NW);
     MSTAMP(299);
     for (int i = 4 * tid; i < L.smem_chain / 4; i += 4 * NT) *reinterpret_cast<f32x4*>(smem + i) = ZERO4;
     __syncthreads();
@@ -1075,8 +968,7 @@ __global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, 
         X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = t0; X.h1 = t1;
         float* srow = grp == 0 ? sg : grp == 1 ? sv : sl;
         float* out = wsm + (grp == 0 ? L.ws.g : grp == 1 ? L.ws.v : L.ws.l) + (size_t)row0 * L.dl;
-        const BSrc nx = grp == 0 ? src_w(L, DF, P, 0, false) : idle;
-        mlp_fwd<RTE, NW, SRC_W>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc ? Kx : L.M, enc && L.M > 0, nx, St,
+        mlp_fwd<RTE, NW>(L, X, L.mlp[m], enc ? xin : xin + L.uoff, L.ldx, enc && L.M > 0, St,
                      [&](int rt, int col0, const f32x4& acc, const f32x4&) {
                          const int n = col0 + c;
                          if (n < L.dl) {
@@ -1127,8 +1019,7 @@ __global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, 
                 }
             }
         };
-        if (mode & 2) mlp_fwd<RTE, NW, SRC_WT>(L, X, DF, sz, lds, L.dl, false, dgrad_src(B, DF, L.L - 1), St, head);
-        else mlp_fwd<RTE, NW, SRC_NONE>(L, X, DF, sz, lds, L.dl, false, src_none(), St, head);
+        mlp_fwd<RTE, NW>(L, X, DF, sz, lds, false, St, head);
     } else {
         for (int li = 0; li < L.L; ++li) __syncthreads();
     }
@@ -1196,7 +1087,6 @@ __global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, 
     }
     // ---- head deltas (plain ELBO: SURVEY.md §8 a-bwd) and the three encoder / prior input-gradient chains
     MSTAMP(306);
-    if (L.L > 1) stream_begin<SRC_WT>(St, dgrad_src(B, L.mlp[m], L.L - 1), NW);
     {
         float* dltT = wsm + L.mlp[m].lay[L.L - 1].dlt_off + row0;
         const int gt = tid & (64 * NW - 1);          // thread index inside my group
