@@ -462,7 +462,7 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
 // per block so that the waits are exact.  blockIdx.z enumerates (MLP, layer, k-tile group, n-tile group) in the MLP order
 // f, g, logv, logl; the result goes to the row tile's gradient slab.
 #ifndef WG_PD
-#define WG_PD 2
+#define WG_PD 1
 #endif
 #define WG_NT 4
 #define WG_KT 4
