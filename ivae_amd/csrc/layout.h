@@ -174,7 +174,7 @@ static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo
     if (L.dd + L.M + 1 > jmax) jmax = L.dd + L.M + 1;
     if (L.dl + 1 > jmax) jmax = L.dl + 1;
     int nw = 4;
-    if ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 64) nw = 8;       // (16: the caller's choice only)
+    if ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 64) nw = jmax > 128 ? 16 : 8;
     if (d->waves) nw = d->waves;
     ivae_tile_geometry(L, tr, nw);
     while (ivae_lds_over(L) && (nw > 4 || tr > 16)) {
