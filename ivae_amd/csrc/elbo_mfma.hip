@@ -138,6 +138,9 @@ struct BSrc {                       // (kept small: it lives in scalar registers
 // of 2 / 4 / 8 blocks.  Every deeper variant was slower (configs[3]: 59 us with this loop, 61 / 61 / 66 / 101 us with
 // groups of 1 / 2 / 4 / 8 blocks carried from product to product; batch 32768: 242 against 252 ... 523 us): the weights
 // come from L2 quickly, and the registers and loads of blocks that do not exist cost more than the latency they hid.
+// Likewise ALL of a tile's fragments requested at once for products of <= 4 blocks (exact counts, one round trip per
+// product): 256 packed models 134 us against 113 us per step -- the registers cost k_chain<2> its second workgroup per CU,
+// and occupancy is what hides the latency of a pack's weights, which come from HBM rather than L2.
 #define ONES4 ((f32x4){1.f, 1.f, 1.f, 1.f})
 struct Stream {           // (diagnostic build: stamps written so far)
     int n;
@@ -147,7 +150,7 @@ struct Stream {           // (diagnostic build: stamps written so far)
 // and every call issues the same number of loads whatever the extents are (a block past them reads range-checked
 // addresses and is never used): the compiler can then count outstanding loads exactly, and a wait for the block that is
 // needed now does not also wait for the one issued after it.
-template <int KIND>
+template <int KIND, bool BIAS = true>
 __device__ __forceinline__ void frag_load(f32x4& dst, float& bias, const BSrc& S, int col0, int blk) {
     int lane = threadIdx.x & 63;
 #ifndef MF_TRANSPARENT
@@ -160,7 +163,7 @@ __device__ __forceinline__ void frag_load(f32x4& dst, float& bias, const BSrc& S
         const int kf = 16 * blk + 4 * q;
         const int sh = kf >= S.hole0 + S.hole ? S.hole : 0;
         dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (j * S.ld + kf - sh) * 4, 0, 0));
-        bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (S.boff + j) * 4, 0, 0));
+        if (BIAS) bias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (S.boff + j) * 4, 0, 0));
     } else {
         const int vo = ((16 * blk + 4 * q) * S.ld + j) * 4;
 #pragma unroll
@@ -189,6 +192,16 @@ __device__ __forceinline__ f32x4 frag_last(const BSrc& S, f32x4 b, int kf, float
 // (compile-time copy).
 // epi(rt, col0, acc, aux): lane (c, q) holds out[16*rt + 4q + r][col0 + c], r = 0..3; aux = pre(rt, col0): global operands
 // of the epilogue (activation derivatives of the dgrad mask), fetched BEFORE the contraction so that they arrive under it.
+// Workgroup barrier between the products of a row chain.  The hand-off is through LDS, so only this wave's LDS traffic
+// has to be complete; global stores of the epilogues are read back (if at all) behind one of the kernels' full
+// __syncthreads() at a stage boundary.
+__device__ __forceinline__ void tile_barrier() {
+#ifdef MF_FULL_BARRIER
+    __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 struct NoPre { __device__ __forceinline__ f32x4 operator()(int, int) const { return ZERO4; } };
 template <int RTE, int NW, int KIND, class EPI, class PRE = NoPre>
 __device__ __forceinline__ void tile_gemm(const float* A, int lda, const BSrc& S, Stream& St, EPI&& epi, PRE&& pre = PRE()) {
@@ -202,24 +215,30 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, const BSrc& S
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) % NW, lane = tid & 63, c = lane & 15, q = lane >> 4;
     const int nblk = up16(S.Kc) >> 4;
     const int kmask = KIND == SRC_W ? S.Kc - 1 : S.K;     // k blocks reaching past it are masked (SRC_W: only the last one)
-    MSTAMPF(2);
-    __syncthreads();                               // the A tile is complete
-    MSTAMPF(3);
-    for (int col0 = 16 * wave; col0 < S.Jt; col0 += NCH) {
-        f32x4 acc[RTE][NA], aux[RTE], bq;
-        float bias = 0.f;
-        frag_load<KIND>(bq, bias, S, col0, 0);
+    // The first fragment (weights: they do not depend on the barrier) and the epilogue operands are requested BEFORE the
+    // barrier, which waits for this wave's LDS traffic only.
+    int col0 = 16 * wave;
+    f32x4 bq, aux[RTE];
+    float bias = 0.f, nob;
+    auto fetch = [&](int col) __attribute__((always_inline)) {
+        frag_load<KIND>(bq, bias, S, col, 0);
 #pragma unroll
-        for (int rt = 0; rt < RTE; ++rt) {
+        for (int rt = 0; rt < RTE; ++rt) aux[rt] = pre(rt, col);
+    };
+    fetch(col0);
+    MSTAMPF(2);
+    tile_barrier();                                // the A tile is complete
+    MSTAMPF(3);
+    while (col0 < S.Jt) {
+        f32x4 acc[RTE][NA];
+#pragma unroll
+        for (int rt = 0; rt < RTE; ++rt)
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[rt][a] = ZERO4;
-            aux[rt] = pre(rt, col0);
-        }
         const float* ap = A + c * lda + 4 * q;
         for (int blk = 0; blk < nblk; ++blk) {
             f32x4 b = bq;
-            float nob;
-            frag_load<KIND>(bq, nob, S, col0, blk + 1);          // (the block past the last one: range-checked, unused)
+            frag_load<KIND, false>(bq, nob, S, col0, blk + 1);      // (the block past the last one: range-checked, unused)
             f32x4 a[RTE];
 #pragma unroll
             for (int rt = 0; rt < RTE; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(ap + 16 * rt * lda + 16 * blk);
@@ -234,6 +253,8 @@ __device__ __forceinline__ void tile_gemm(const float* A, int lda, const BSrc& S
 #pragma unroll
         for (int rt = 0; rt < RTE; ++rt) epi(rt, col0, NA == 2 ? acc[rt][0] + acc[rt][NA - 1] : acc[rt][0], aux[rt]);
         MSTAMPF(6);
+        col0 += NCH;
+        if (col0 < S.Jt) fetch(col0);              // (wave-uniform)
     }
 }
 
@@ -880,8 +901,11 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_enc(Layout L, IvaeCoef C, const
 #ifndef CH_NW
 #define CH_NW 4
 #endif
+#ifndef CH_OCC
+#define CH_OCC 6          // waves per SIMD the register allocation leaves room for: two 12-wave workgroups per CU
+#endif
 template <int RTE>
-__global__ __launch_bounds__(64 * CH_NW * 3) void k_chain(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
+__global__ __launch_bounds__(64 * CH_NW * 3) __attribute__((amdgpu_waves_per_eu(CH_OCC, CH_OCC))) void k_chain(Layout L, IvaeCoef C, int mode, const float* __restrict__ params,
                                                           const float* __restrict__ x, const float* __restrict__ u,
                                                           const float* __restrict__ eps, float* __restrict__ z_out,
                                                           float* __restrict__ ws) {

@@ -61,6 +61,9 @@ struct Layout {
 #ifndef IVAE_CHAIN_MIN_TILES
 #define IVAE_CHAIN_MIN_TILES 128
 #endif
+#ifndef IVAE_CHAIN_MAX_COLS
+#define IVAE_CHAIN_MAX_COLS 64
+#endif
 #ifndef IVAE_CHAIN_LDS_LIMIT
 #define IVAE_CHAIN_LDS_LIMIT (128 * 1024)
 #endif    // larger row-chain tiles leave the three-kernel path (one chain per workgroup)
@@ -92,6 +95,9 @@ static inline void ivae_tile_geometry(Layout& L, int tr, int nw) {
         // the instruction stream on each): the fused kernel is for launches that fill the chip anyway
         if (IVAE_CHAIN_MIN_TILES && (int64_t)((L.B + tr - 1) / tr) * L.n_models < IVAE_CHAIN_MIN_TILES) L.smem_chain = 0;
         if (tr > 32) L.smem_chain = 0;            // (its 12-wave workgroups have 170 registers per lane: two row tiles at most)
+        // its chains are groups of 4 waves = 64 output columns per pass: wider layers run faster as 8-wave workgroups of
+        // their own (measured, H = 100: 64 packed models 104 against 111 us per step, batch 16384 170 against 189 us)
+        if (IVAE_CHAIN_MAX_COLS && L.maxh > IVAE_CHAIN_MAX_COLS) L.smem_chain = 0;      // (maxh: widest OUTPUT of any layer)
     }
 }
 
@@ -167,14 +173,13 @@ static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo
     int tr = 32;
     while (tr > 16 && (int64_t)((L.B + tr - 1) / tr) * L.n_models < 512) tr >>= 1;
     if (d->tile_rows) tr = d->tile_rows;                           // caller's choice (validated by ivae_check_dims)
-    // waves per workgroup: 4 when the launch fills the chip by itself (several workgroups share a CU and hide each
-    // other's latencies) or no product streams more than 64 output columns; otherwise a wider workgroup takes
-    // 128 / 256 columns per chunk, so that a short dependent chain of layers needs fewer chunk round trips
-    int jmax = L.H + 1;                                            // widest streamed extent over all products
-    if (L.dd + L.M + 1 > jmax) jmax = L.dd + L.M + 1;
-    if (L.dl + 1 > jmax) jmax = L.dl + 1;
+    // waves per workgroup: 4 when no product streams more than 64 output columns; wider layers take 8 (128 columns per
+    // pass; measured faster than 4 and than 16 on chip-filling launches too: H = 200, batch 16384: 0.40 against 0.43 /
+    // 0.43 ms), and 16 when the launch leaves CUs empty and a layer is wider than 128, so that a short dependent chain of
+    // layers passes fewer barriers
+    const int jmax = L.maxh;                                       // widest output (streamed columns) over all products
     int nw = 4;
-    if ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 64) nw = jmax > 128 ? 16 : 8;
+    if (jmax > 64) nw = ((int64_t)((L.B + tr - 1) / tr) * L.n_models < 256 && jmax > 128) ? 16 : 8;
     if (d->waves) nw = d->waves;
     ivae_tile_geometry(L, tr, nw);
     while (ivae_lds_over(L) && (nw > 4 || tr > 16)) {

@@ -1,4 +1,15 @@
 #!/bin/bash
-# build_variant.sh <name> <extra -D flags...>: library variant under build/ for timing experiments (never shipped)
+# build_variant.sh <name> [-Dflags...]: build/libivae_<name>.so = the library with elbo_mfma.hip and capi.hip (which builds
+# the layouts) compiled with extra flags; the other objects are the tree's own (run `make` first).
+# Use with IVAE_AMD_LIB=/root/repo/build/libivae_<name>.so.
+set -e
 name=$1; shift
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -shared ivae_amd/csrc/*.hip -o build/libivae_$name.so
+cd "$(dirname "$0")/.."
+mkdir -p build
+for f in elbo_mfma capi; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" -c ivae_amd/csrc/$f.hip -o build/${f}_$name.o &
+done
+wait
+others=$(ls ivae_amd/csrc/*.o | grep -v -e elbo_mfma.o -e capi.o)
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 build/elbo_mfma_$name.o build/capi_$name.o $others -o build/libivae_$name.so
+rm -f build/elbo_mfma_$name.o build/capi_$name.o

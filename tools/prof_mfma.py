@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Phase anatomy of k_fwd_enc / k_dec / k_bwd_enc from the s_memtime stamps of the -DMF_PROF diagnostic build.
-usage: IVAE_AMD_LIB=build/libivae_mfprof.so prof_mfma.py cfg"""
+usage: IVAE_AMD_LIB=/root/repo/build/libivae_mfprof.so [PROF_MODELS=K] prof_mfma.py cfg [fwd|bwd|step] [part]
+PROF_MODELS=K packs K copies of the model (the stamps are those of workgroup (0, 0) in the loaded launch)."""
 import ctypes as C
 import os
 import sys
@@ -17,37 +18,39 @@ dev = torch.device("cuda:0")
 shape, B, ck, N = CFG[name]
 ck = dict(ck, pairwise=False)
 g = torch.Generator(device=dev).manual_seed(0)
-params = (torch.rand(shape.n_params(), generator=g, device=dev) - .5) * .2
-x = torch.randn(B, shape.data_dim, generator=g, device=dev)
+K = int(os.environ.get("PROF_MODELS", "1"))
+params = (torch.rand(K * shape.n_params(), generator=g, device=dev) - .5) * .2
+x = torch.randn(K, B, shape.data_dim, generator=g, device=dev)
 u = None
 if shape.aux_dim:
-    u = torch.zeros(B, shape.aux_dim, device=dev)
-    u[torch.arange(B, device=dev), torch.randint(0, shape.aux_dim, (B,), generator=g, device=dev)] = 1
-eps = torch.randn(B, shape.latent_dim, generator=g, device=dev)
+    lab = torch.randint(0, shape.aux_dim, (K, B), generator=g, device=dev)
+    u = torch.zeros(K, B, shape.aux_dim, device=dev).scatter_(2, lab.unsqueeze(-1), 1.)
+eps = torch.randn(K, B, shape.latent_dim, generator=g, device=dev)
+if K == 1:
+    x, eps, u = x[0], eps[0], None if u is None else u[0]
 coef = ops.make_coef(N=N, global_batch=B, **ck)
 ws = ops.Workspace()
 for _ in range(3):
-    ops.forward(shape, coef, params, x, u, eps, ws)
-    ops.backward(shape, coef, params, x, u, eps, ws)
+    ops.forward(shape, coef, params, x, u, eps, ws, n_models=K)
+    ops.backward(shape, coef, params, x, u, eps, ws, n_models=K)
 buf = torch.zeros(4000, dtype=torch.int64, device=dev)
 L = _lib.lib()
 L.ivae_debug_set_prof_mf.argtypes = [C.c_void_p]
 torch.cuda.synchronize()
 if which == "step":
-    z = torch.empty(B, shape.latent_dim, device=dev)
     for _ in range(3):
-        ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws)
+        ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=K)
     torch.cuda.synchronize()
     L.ivae_debug_set_prof_mf(C.c_void_p(buf.data_ptr()))
-    ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws)
+    ops.elbo_fwd_bwd(shape, coef, params, x, u, eps, ws, n_models=K)
 elif which == "fwd":
     L.ivae_debug_set_prof_mf(C.c_void_p(buf.data_ptr()))
-    ops.forward(shape, coef, params, x, u, eps, ws)
+    ops.forward(shape, coef, params, x, u, eps, ws, n_models=K)
 else:
-    ops.forward(shape, coef, params, x, u, eps, ws)
+    ops.forward(shape, coef, params, x, u, eps, ws, n_models=K)
     torch.cuda.synchronize()
     L.ivae_debug_set_prof_mf(C.c_void_p(buf.data_ptr()))
-    ops.backward(shape, coef, params, x, u, eps, ws)
+    ops.backward(shape, coef, params, x, u, eps, ws, n_models=K)
 torch.cuda.synchronize()
 L.ivae_debug_set_prof_mf(C.c_void_p(0))
 b = buf.cpu().view(-1, 2).tolist()

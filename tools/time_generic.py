@@ -18,6 +18,8 @@ CFG = {
     "cfg3": (ops.ModelShape(20, 20, 200, 50, 3, "lrelu", .1), 4096, dict(pairwise=False), 1000000),
     "cfgw": (ops.ModelShape(10, 10, 40, 200, 3, "lrelu", .1), 256, dict(pairwise=False), 40000),   # IVAE_wrapper defaults (wrappers.py:14-16)
     "cfg3L": (ops.ModelShape(20, 20, 200, 50, 3, "lrelu", .1), 32768, dict(pairwise=False), 1000000),   # chip-filling batch
+    "h100L": (ops.ModelShape(5, 5, 40, 100, 3, "xtanh", .1), 16384, dict(pairwise=False), 1000000),      # yaml shapes, chip-filling batch, plain
+    "h200L": (ops.ModelShape(10, 10, 40, 200, 3, "lrelu", .1), 16384, dict(pairwise=False), 1000000),   # wrapper shapes, chip-filling batch
     "cfg3p": (ops.ModelShape(20, 20, 200, 50, 3, "lrelu", .1), 4096, dict(a=1., b=1., c=2., d=1., pairwise=True), 1000000),
 }
 
