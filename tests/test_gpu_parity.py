@@ -190,11 +190,13 @@ def test_module_works_with_stock_torch_adam_and_forward():
     assert torch.isfinite(e1) and z1.shape == (64, 10)
 
 
-@pytest.mark.parametrize("nr,nc,d", [(37, 101, 6), (300, 1111, 20), (513, 64, 32), (70, 130, 40), (1, 1, 1)])
+@pytest.mark.parametrize("nr,nc,d", [(37, 101, 6), (300, 1111, 20), (513, 64, 32), (70, 130, 40), (1, 1, 1),
+                                     (2100, 2309, 7), (2050, 2048, 20), (2048, 2100, 24)])
 def test_pairwise_rectangular_matches_oracle(nr, nc, d):
     """Rows != columns (the data-parallel shard shape): ivae_pairwise vs explicit numpy, for the sliced kernels
-    (d <= 32: several column / row slices, ragged last slice, d a multiple of 4 or not) and the wave-per-row kernels
-    (d = 40); the degenerate 1 x 1 x 1 problem too."""
+    (d <= 32: several column / row slices, ragged last slice, d a multiple of 4 or not; also at extents > 2048, where
+    every slice count is at its chip-filling value) and the wave-per-row kernels (d = 40); the degenerate 1 x 1 x 1
+    problem too."""
     rng = np.random.RandomState(3)
     z = rng.randn(nr, d).astype(np.float32)
     g = rng.randn(nc, d).astype(np.float32)
