@@ -536,7 +536,7 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& J, int kt0, int nt0)
                 fb[u][kt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (jj[kt] * J.Bp + ro) * 4, 0, 0));
             } else {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) fb[u][kt][x] = base[kt][(long)min(ro + x, last_row) * rstride[kt]];
+                for (int x = 0; x < 4; ++x) fb[u][kt][x] = base[kt][__mul24(min(ro + x, last_row), rstride[kt])];   // (< 2^31 bytes: ivae_check_dims)
             }
         }
     };
@@ -583,18 +583,22 @@ __device__ __forceinline__ void wgrad_block(const WgradJob& J, int kt0, int nt0)
     }
     WSTAMP(4);
     // results -> the slab: branch-free, an element outside the layer's (N, K + 1) gets an offset past the slab's range
-    // and the buffer store drops it
+    // and the buffer store drops it.  Byte offsets advance by a per-lane stride (a weight column: K floats per output row;
+    // the bias: one), so an element costs one 24-bit multiply-add, a compare against a scalar and a select.
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)J.slab, 0, J.slab_bytes, 0x00020000);
+    const int n0 = 16 * nt0 + 4 * q;
 #pragma unroll
     for (int kt = 0; kt < WG_KT; ++kt) {
         const int j = jj[kt];
+        const int stride4 = j < J.K ? 4 * J.K : 4;
+        const int el0 = (j < J.K ? 4 * (J.w_off + j) : 4 * J.b_off) + __mul24(n0, stride4);
+        const int nlim = j <= J.K ? J.N - n0 : 0;             // rows n0 + e with e < nlim exist
 #pragma unroll
         for (int t = 0; t < WG_NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = 16 * (nt0 + t) + 4 * q + r;
-                const int el = j < J.K ? J.w_off + n * J.K + j : J.b_off + n;
-                const int off = (n < J.N && j <= J.K) ? el * 4 : 0x7ffffff0;
+                const int e = 16 * t + r;
+                const int off = e < nlim ? el0 + __mul24(e, stride4) : 0x7ffffff0;
                 const float val = acc[t][kt][r];       // (bit_cast of a vector element reads element 0: go through a scalar)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(val), rg, off, 0, 0);
             }
@@ -607,6 +611,9 @@ __host__ __device__ __forceinline__ int wgrad_kgroups(int din) { return ((din + 
 __host__ __device__ __forceinline__ int wgrad_ngroups(int dout) { return ((dout + 15) / 16 + WG_NT - 1) / WG_NT; }
 
 #define WG_WAVES 4         // jobs (waves) per workgroup: the four waves of a workgroup sit on the four SIMDs of its CU
+#ifdef WG_OCC
+__attribute__((amdgpu_waves_per_eu(WG_OCC, WG_OCC)))
+#endif
 __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(Layout L, const float* __restrict__ x, const float* __restrict__ u,
                                               float* __restrict__ ws, float* __restrict__ slabs, long slab_stride) {
     WSTAMP(0);
