@@ -12,6 +12,7 @@ full-data evaluation on a *sampled* z (runners/ivae.py:118-123).  Runs of one la
 the fused persistent kernel where it covers the shape, the generic MFMA kernels otherwise.
 """
 import argparse
+from concurrent.futures import ThreadPoolExecutor
 import json
 import os
 import time
@@ -86,16 +87,20 @@ def evaluate_pack(shape, params, x, u, s_true, rows_per_call=8192, seed=0):
 
 
 def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2, hidden=50, data="host",
-              device=None, rank=0, world=1, log=None):
+              device=None, rank=0, world=1, log=None, concurrent=True):
     """Runs this rank's share of the (dim, seed) grid; returns (local run ids, local MCCs, seconds spent training,
-    training steps x models done)."""
+    training steps x models done).  concurrent: the packs of the different latent dimensions train at the same time, each
+    on a HIP stream of its own -- a 64-model pack of the fused kernel occupies 64 of the 256 CUs and a 64-model pack of
+    the generic kernels is latency-bound, so one pack at a time leaves most of the chip idle; the packs are independent,
+    their results do not depend on the interleaving."""
     device = device or torch.device("cuda", 0)
     runs = [(d, s) for d in dims for s in range(n_seeds)]
     lo, hi = model_range(len(runs), rank, world)
     mine = runs[lo:hi]
     mcc_local = np.zeros(hi - lo)
-    t_train, work = 0.0, 0
     N = n_seg * n_per_seg
+    steps = epochs * (N // batch)
+    packs = []
     for d in sorted({r[0] for r in mine}):
         idx = [i for i, r in enumerate(mine) if r[0] == d]
         seeds = [mine[i][1] for i in idx]
@@ -108,18 +113,37 @@ def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2
         cls = FusedPackedTrainer if fused else PackedTrainer
         tr = cls(shape, n_models=len(seeds), batch=batch, lr=lr, seed=1000 * d + seeds[0], device=device)
         tr.set_data(x, u)
-        steps = epochs * (N // batch)
+        packs.append(dict(d=d, idx=idx, shape=shape, fused=fused, tr=tr, x=x, u=u, s=s_true, n=len(seeds)))
+    t_train, work = 0.0, 0
+    if concurrent and len(packs) > 1:
+        # generic packs first: thousands of short launches each, enqueued while the earlier packs already run
+        order = sorted(packs, key=lambda p: (p["fused"], -p["d"]))
+        streams = [torch.cuda.Stream(device) for _ in order]
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        tr.run(steps)            # fused: ivae_train_steps launches; generic: one ivae_elbo_adam_steps call per epoch
+        def train(p, st):      # a host thread per pack: a launch call blocks while its stream's queue is full, and the
+            torch.cuda.set_device(device)       # library calls (a whole epoch each) run without the interpreter lock
+            with torch.cuda.stream(st):
+                p["tr"].run(steps)       # fused: ivae_train_steps launches; generic: one ivae_elbo_adam_steps call per epoch
+        with ThreadPoolExecutor(len(order)) as pool:
+            for f in [pool.submit(train, p, st) for p, st in zip(order, streams)]:
+                f.result()
         torch.cuda.synchronize(device)
-        t_train += time.perf_counter() - t0
-        work += steps * len(seeds)
-        m = evaluate_pack(shape, tr.params, x, u, s_true, seed=d)
-        mcc_local[idx] = m
+        t_train = time.perf_counter() - t0
+    else:
+        for p in packs:
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            p["tr"].run(steps)
+            torch.cuda.synchronize(device)
+            t_train += time.perf_counter() - t0
+    for p in packs:
+        work += steps * p["n"]
+        m = evaluate_pack(p["shape"], p["tr"].params, p["x"], p["u"], p["s"], seed=p["d"])
+        mcc_local[p["idx"]] = m
         if log:
             log("rank %d: d=%d, %d runs, %s, %d steps: MCC mean %.3f (min %.3f, max %.3f)" % (
-                rank, d, len(seeds), "fused" if fused else "generic", steps, m.mean(), m.min(), m.max()))
+                rank, p["d"], p["n"], "fused" if p["fused"] else "generic", steps, m.mean(), m.min(), m.max()))
     return (lo, hi), mcc_local, t_train, work
 
 
@@ -136,6 +160,8 @@ def main():
                     help="host (default): the bit-exact numpy generator of data/data.py, as north_star asks (seconds per "
                          "dataset); device: a throughput-only stand-in drawn on the GPU WITHOUT the generator's "
                          "condition-number rejection -- its MCCs are not on reference inputs")
+    ap.add_argument("--serial", action="store_true", help="train one pack (latent dimension) at a time instead of all "
+                                                          "of them concurrently on separate streams")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,7 +174,7 @@ def main():
     t0 = time.perf_counter()
     (lo, hi), mcc, t_train, work = run_sweep(dims, args.seeds, args.epochs, args.ns, args.nps, args.batch, args.lr,
                                              data=args.data, device=dev, rank=rank, world=world,
-                                             log=lambda s: print(s, flush=True))
+                                             log=lambda s: print(s, flush=True), concurrent=not args.serial)
     n_runs = len(dims) * args.seeds
     allm = gather_model_results(torch.from_numpy(mcc).to(dev), n_runs).cpu().numpy()
     stats = torch.tensor([t_train, float(work)], device=dev, dtype=torch.float64)
@@ -165,6 +191,7 @@ def main():
             per_dim[str(d)] = {"mcc_mean": round(float(m.mean()), 4), "mcc_std": round(float(m.std()), 4)}
         print(json.dumps({"sweep": "iVAE seeds x dims, packed runs", "n_runs": n_runs, "n_gpus": world,
                           "epochs": args.epochs, "batch": args.batch,
+                          "packs": "one at a time" if args.serial else "concurrent, one HIP stream per latent dimension",
                           "data": ("host numpy generator (bit-exact data/data.py)" if args.data == "host" else
                                    "device stand-in, NOT the reference generator (no condition-number rejection)"),
                           "train_samples_per_s": round(work * args.batch / t_train, 1),

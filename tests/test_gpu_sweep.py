@@ -21,6 +21,18 @@ def test_small_sweep_trains_and_scores_every_run():
     assert ops.train_steps_supported(ops.ModelShape(5, 5, 40, 50, 3, "lrelu", .1), 64)
 
 
+def test_concurrent_packs_equal_serial_packs():
+    """The packs of a sweep train concurrently on one HIP stream each (the default) or one at a time: the packs are
+    independent and every kernel sums in a fixed order, so every run's score is the same to the last bit."""
+    from ivae_amd.sweep import run_sweep
+    dev = torch.device("cuda:0")
+    kw = dict(n_seeds=3, epochs=2, n_seg=40, n_per_seg=48, batch=64, device=dev)
+    _, mcc_c, _, work_c = run_sweep([5, 12, 20], concurrent=True, **kw)
+    _, mcc_s, _, work_s = run_sweep([5, 12, 20], concurrent=False, **kw)
+    assert work_c == work_s
+    assert np.array_equal(mcc_c, mcc_s)
+
+
 def test_two_rank_split_covers_the_grid_once():
     """Rank shares of the run list are disjoint and complete (no GPU work: the partition rule only)."""
     from ivae_amd.dist import model_range
