@@ -611,11 +611,14 @@ __host__ __device__ __forceinline__ int wgrad_kgroups(int din) { return ((din + 
 __host__ __device__ __forceinline__ int wgrad_ngroups(int dout) { return ((dout + 15) / 16 + WG_NT - 1) / WG_NT; }
 
 #define WG_WAVES 4         // jobs (waves) per workgroup: the four waves of a workgroup sit on the four SIMDs of its CU
+#define RED_W 16           // waves of a k_reduce block (its loss block's thread map is reproduced below)
+__device__ __forceinline__ float loss_partial(const Layout& L, const IvaeCoef& C, const float* wsm, int t, int stride);
 #ifdef WG_OCC
 __attribute__((amdgpu_waves_per_eu(WG_OCC, WG_OCC)))
 #endif
 __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(Layout L, const float* __restrict__ x, const float* __restrict__ u,
-                                              float* __restrict__ ws, float* __restrict__ slabs, long slab_stride) {
+                                              float* __restrict__ ws, float* __restrict__ slabs, long slab_stride,
+                                              IvaeCoef C, float* __restrict__ loss_out) {
     WSTAMP(0);
     warm_kernel_args();
     WSTAMP(8);
@@ -637,34 +640,50 @@ __global__ __launch_bounds__(64 * WG_WAVES) void k_wgrad(Layout L, const float* 
         }
     }
     WSTAMP(6);
-    if (m < 0) return;
-    const MlpDesc& D = L.mlp[m];
-    const int kg = wgrad_kgroups(D.lay[li].din);
-    const int kt0 = (job % kg) * WG_KT, nt0 = (job / kg) * WG_NT;
-    float* wsm = ws + (size_t)model * L.ws.per_model;
-    WgradJob J;
-    J.N = D.lay[li].dout; J.K = D.lay[li].din; J.Bp = L.Bp; J.nrows = nrows;
-    J.dlt = wsm + D.lay[li].dlt_off + row0;
-    { const long lim = L.ws.per_model - (D.lay[li].dlt_off + row0); J.dlt_lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
-    J.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.slab_ld;
-    J.slab_bytes = L.n_params * 4; J.w_off = D.lay[li].w_off; J.b_off = D.lay[li].b_off;
-    J.actT = wsm; J.act_lim = 0; J.in_a = J.in_b = wsm; J.na = J.K; J.nb = 0;
+    if (m >= 0) {
+        const MlpDesc& D = L.mlp[m];
+        const int kg = wgrad_kgroups(D.lay[li].din);
+        const int kt0 = (job % kg) * WG_KT, nt0 = (job / kg) * WG_NT;
+        float* wsm = ws + (size_t)model * L.ws.per_model;
+        WgradJob J;
+        J.N = D.lay[li].dout; J.K = D.lay[li].din; J.Bp = L.Bp; J.nrows = nrows;
+        J.dlt = wsm + D.lay[li].dlt_off + row0;
+        { const long lim = L.ws.per_model - (D.lay[li].dlt_off + row0); J.dlt_lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL); }
+        J.slab = slabs + (size_t)model * slab_stride + (size_t)blockIdx.x * L.slab_ld;
+        J.slab_bytes = L.n_params * 4; J.w_off = D.lay[li].w_off; J.b_off = D.lay[li].b_off;
+        J.actT = wsm; J.act_lim = 0; J.in_a = J.in_b = wsm; J.na = J.K; J.nb = 0;
 #ifdef MF_PROF
-    asm volatile("" ::"s"(J.N), "s"(J.K), "s"(J.dlt), "s"(J.w_off), "s"(J.b_off), "s"(J.dlt_lim));
-    WSTAMP(7);
+        asm volatile("" ::"s"(J.N), "s"(J.K), "s"(J.dlt), "s"(J.w_off), "s"(J.b_off), "s"(J.dlt_lim));
+        WSTAMP(7);
 #endif
-    if (li > 0) {
-        J.actT = wsm + D.lay[li - 1].pre_off + row0;
-        const long lim = L.ws.per_model - (D.lay[li - 1].pre_off + row0);
-        J.act_lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL);
-        wgrad_block<false>(J, kt0, nt0);
-    } else {
-        const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
-        const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : xm;
-        if (m == IVAE_MLP_F) { J.in_a = wsm + L.ws.z + (size_t)row0 * L.dl; J.na = L.dl; J.in_b = J.in_a; J.nb = 0; }
-        else if (m == IVAE_MLP_LOGL) { J.in_a = um; J.na = L.M; J.in_b = um; J.nb = 0; }
-        else { J.in_a = xm; J.na = L.dd; J.in_b = um; J.nb = L.M; }
-        wgrad_block<true>(J, kt0, nt0);
+        if (li > 0) {
+            J.actT = wsm + D.lay[li - 1].pre_off + row0;
+            const long lim = L.ws.per_model - (D.lay[li - 1].pre_off + row0);
+            J.act_lim = (unsigned)(lim < 0x3fffffffL ? lim : 0x3fffffffL);
+            wgrad_block<false>(J, kt0, nt0);
+        } else {
+            const float* xm = x + ((size_t)model * L.B + row0) * L.dd;
+            const float* um = L.M > 0 ? u + ((size_t)model * L.B + row0) * L.M : xm;
+            if (m == IVAE_MLP_F) { J.in_a = wsm + L.ws.z + (size_t)row0 * L.dl; J.na = L.dl; J.in_b = J.in_a; J.nb = 0; }
+            else if (m == IVAE_MLP_LOGL) { J.in_a = um; J.na = L.M; J.in_b = um; J.nb = 0; }
+            else { J.in_a = xm; J.na = L.dd; J.in_b = um; J.nb = L.M; }
+            wgrad_block<true>(J, kt0, nt0);
+        }
+    }
+    // loss of the model (loss_out != null: the gradient needs no slab reduction and the row chains ran in k_chain, which
+    // sees one tile's rows only -- no k_reduce launch follows): the model's first workgroup sums the per-row terms with
+    // k_reduce's thread map and order (same bits), 64 * RED_W virtual threads on its 256 real ones
+    if (loss_out && blockIdx.x == 0 && blockIdx.z == 0) {
+        __shared__ float red[64 * RED_W];
+        const float* wsl = ws + (size_t)model * L.ws.per_model;
+        const int tid = threadIdx.x;
+        for (int vt = tid; vt < 64 * RED_W; vt += 64 * WG_WAVES) red[vt] = loss_partial(L, C, wsl, vt, 64 * RED_W);
+        __syncthreads();
+        for (int sft = 32 * RED_W; sft > 0; sft >>= 1) {
+            for (int vt = tid; vt < sft; vt += 64 * WG_WAVES) red[vt] += red[vt + sft];
+            __syncthreads();
+        }
+        if (tid == 0) loss_out[model] = -red[0] / (float)C.global_batch;
     }
 }
 
@@ -1145,8 +1164,7 @@ __global__ __launch_bounds__(64 * CH_NW * 3) __attribute__((amdgpu_waves_per_eu(
 // Sum the per-tile slabs into grads and reduce the loss.  A block sums 64 parameters: wave g adds the tiles
 // t = g, g+4, ... with four independent accumulators (loads in flight), then the partials are combined in a fixed
 // order, so the result does not depend on scheduling.
-#define RED_P 256
-#define RED_W 16          // waves of a k_reduce block: wave g sums the slabs g, g + 16, ...
+#define RED_P 256          // (RED_W = 16 waves per block, defined above: wave g sums the slabs g, g + 16, ...)
 template <bool ADAM>
 __global__ __launch_bounds__(64 * RED_W) void k_reduce(Layout L, IvaeCoef C, const float* __restrict__ ws,
                                                        float* __restrict__ grads, float* __restrict__ loss_out, AdamFuse F) {
@@ -1223,7 +1241,8 @@ static hipError_t launch_t(const Layout& L, const IvaeCoef& C, int what, const f
         if ((e = set_smem((const void*)k_dec<RTE, NW>, L.smem_dec, cur_dec)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_dec<RTE, NW>), dim3(L.n_tiles, L.n_models), dim3(NT), L.smem_dec, st, L, C, what, params, x, eps, z_out, ws);
     } else if (what == 5) {     // weight gradients of every layer of every MLP
-        hipLaunchKernelGGL(k_wgrad, dim3(L.n_wtiles, L.n_models, (L.wg_total + WG_WAVES - 1) / WG_WAVES), dim3(64 * WG_WAVES), 0, st, L, x, u, ws, slabs, slab_stride);
+        hipLaunchKernelGGL(k_wgrad, dim3(L.n_wtiles, L.n_models, (L.wg_total + WG_WAVES - 1) / WG_WAVES), dim3(64 * WG_WAVES), 0, st, L, x, u, ws, slabs, slab_stride,
+                           C, z_out /* phase 5: the loss output, or null */);
     } else {                    // encoder / prior input-gradient chains
         if ((e = set_smem((const void*)k_bwd_enc<RTE, NW>, L.smem_benc, cur_benc)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_bwd_enc<RTE, NW>), dim3(L.n_tiles, L.n_models, nz), dim3(NT), L.smem_benc, st, L, C, params, x, u, eps, ws,
@@ -1292,12 +1311,11 @@ hipError_t launch_backward(const Layout& L, const IvaeCoef& C, const float* para
     if (!enc_bwd_done &&
         (e = launch_phase(L, C, 4, params, x, u, eps, nblk_p == 0 ? loss_out : nullptr, ws, grads, st)) != hipSuccess)
         return e;
-    if ((e = launch_phase(L, C, 5, params, x, u, eps, nullptr, ws, grads, st)) != hipSuccess) return e;
-    if (nblk_p == 0 && !enc_bwd_done) return hipSuccess;
-    if (nblk_p == 0) {           // (the row-chain kernel has no view of the other tiles' rows: k_reduce's loss block alone)
-        hipLaunchKernelGGL(k_reduce<false>, dim3(1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out, AdamFuse{});
-        return hipGetLastError();
-    }
+    // no slabs and the row chains ran in k_chain (which sees one tile's rows only): k_wgrad's first workgroup of a model
+    // also reduces its loss
+    if ((e = launch_phase(L, C, 5, params, x, u, eps, nblk_p == 0 && enc_bwd_done ? loss_out : nullptr, ws, grads, st)) != hipSuccess)
+        return e;
+    if (nblk_p == 0) return hipSuccess;
     if (fuse && L.n_models <= ADAM_MODELS_PER_LAUNCH) {
         hipLaunchKernelGGL(k_reduce<true>, dim3(nblk_p + 1, L.n_models), dim3(64 * RED_W), 0, st, L, C, ws, grads, loss_out, *fuse);
         if (fused) *fused = true;
