@@ -239,6 +239,33 @@ def test_packed_models_equal_individual_runs(case):
         assert torch.equal(l1[0], loss[m]) and torch.equal(z1, z[m]) and torch.equal(g1, grads[m])
 
 
+def test_large_pack_through_the_row_chain_agrees_with_small_packs():
+    """96 packed models of the configs[1] shape go through k_chain and a one-slab k_wgrad, whose first workgroup per
+    model also sums the loss (1152 weight-gradient jobs fill the chip with one 128-row tile per model); 3 models go
+    through k_fwd_enc / k_dec / k_bwd_enc and four 16-row gradient slabs, where k_reduce sums it.  z is row-local and
+    bit-equal; the losses agree to 1e-6 (the two paths add a row's per-feature density terms in different orders) and
+    so do the gradients (their batch sums are split differently)."""
+    from ivae_amd.trainer import init_packed_params
+    d = dev()
+    shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
+    K, B = 96, 64
+    g = torch.Generator(device=d).manual_seed(5)
+    P = init_packed_params(shape, K, 3, d)
+    x = torch.randn(K, B, 10, generator=g, device=d)
+    lab = torch.randint(0, 40, (K, B), generator=g, device=d)
+    u = torch.zeros(K, B, 40, device=d).scatter_(2, lab.unsqueeze(-1), 1.)
+    eps = torch.randn(K, B, 10, generator=g, device=d)
+    co = ops.make_coef(N=40000., global_batch=B)
+    loss, z, grads = ops.elbo_fwd_bwd(shape, co, P, x, u, eps, ops.Workspace(), n_models=K)
+    grads = grads.view(K, -1)
+    for m0 in (0, 45, 93):
+        l3, z3, g3 = ops.elbo_fwd_bwd(shape, co, P.view(K, -1)[m0:m0 + 3].contiguous().view(-1), x[m0:m0 + 3].contiguous(),
+                                      u[m0:m0 + 3].contiguous(), eps[m0:m0 + 3].contiguous(), ops.Workspace(), n_models=3)
+        assert torch.equal(z3, z[m0:m0 + 3])
+        assert relmax(l3.cpu().numpy(), loss[m0:m0 + 3].cpu().numpy()) < 1e-6
+        assert relmax(g3.view(3, -1).cpu().numpy(), grads[m0:m0 + 3].cpu().numpy()) < 1e-6
+
+
 def test_data_parallel_shards_sum_to_full_batch():
     """Row shards with global_batch = B: partial losses / grads add up to the full-batch result."""
     c = Case("ivae_plain_cfg4s")
