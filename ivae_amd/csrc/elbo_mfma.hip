@@ -107,6 +107,11 @@ __device__ __forceinline__ void act_both(float p, int act, float slope, float& h
     }
 }
 
+// Leaky ReLU with a slope >= 0: the derivative is a function of the activation's sign (h > 0 <=> p > 0), so the forward
+// pass does not store it and the backward pass reads the activation plane instead -- a quarter of the row chains' global
+// stores (a pack of models is bound by that traffic, not by arithmetic).
+__device__ __forceinline__ bool der_from_act(const Layout& L) { return L.act == IVAE_ACT_LRELU && L.slope >= 0.f; }
+
 // ------------------------------------------------------------------------------ streamed operand
 // Source of the register-streamed operand Bm[j][k] (j: output column, k: contraction index) of one product.
 //   SRC_W    forward:  Bm[j][k] = W[j][k] (W is (J, K) row-major at p), Bm[j][K] = bias[j] (at p + d2): the A tiles
@@ -315,7 +320,7 @@ __device__ __forceinline__ void mlp_fwd(const Layout& L, const FwdCtx& X, const 
                         dst[(r0 + r) * L.ldh + n] = h;
                     }
                     *reinterpret_cast<f32x4*>(actT + (size_t)n * L.Bp + r0) = hv;
-                    *reinterpret_cast<f32x4*>(derT + (size_t)n * L.Bp + r0) = dv;
+                    if (!der_from_act(L)) *reinterpret_cast<f32x4*>(derT + (size_t)n * L.Bp + r0) = dv;
                 }
             });
             cur = dst;
@@ -429,13 +434,20 @@ __device__ __forceinline__ void mlp_bwd(const Layout& L, const BwdCtx& X, const 
     // activation derivatives of a product's output rows (the dgrad mask), feature-major in the workspace
     struct DerLoad {
         const float* p; int K, Bp, c, q;
+        bool from_act; float slope;      // p holds the activations themselves: act' = 1 where h > 0, else the slope
         __device__ __forceinline__ f32x4 operator()(int rt, int col0) const {
-            return *reinterpret_cast<const f32x4*>(p + (size_t)min(col0 + c, K - 1) * Bp + 16 * rt + 4 * q);
+            f32x4 d = *reinterpret_cast<const f32x4*>(p + (size_t)min(col0 + c, K - 1) * Bp + 16 * rt + 4 * q);
+            if (from_act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = d[r] > 0.f ? 1.f : slope;
+            }
+            return d;
         }
     };
     auto der_of = [&](int li) {          // of the hidden layer that feeds layer li (li >= 1); li < 1: any valid source, unused
         const int l = max(li, 1);
-        return DerLoad{X.wsm + D.lay[l - 1].der_off + X.row0, D.lay[l].din, L.Bp, c, q};
+        const bool fa = der_from_act(L);
+        return DerLoad{X.wsm + (fa ? D.lay[l - 1].pre_off : D.lay[l - 1].der_off) + X.row0, D.lay[l].din, L.Bp, c, q, fa, L.slope};
     };
     for (int t = 0; t < n_prod; ++t) {
         const int li = L.L - 1 - t;
