@@ -249,6 +249,8 @@ def main():
             dst.copy_(src)
         tr.t = t_keep
     advance(args.warmup, False)
+    if fused:      # the events of the timed launches exist before the timed region starts
+        tr.prepare_timing((args.steps + tr.CHUNK - 1) // tr.CHUNK + 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

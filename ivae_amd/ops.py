@@ -1,5 +1,6 @@
 """Tensor-level entry points over the C ABI.  PyTorch supplies device memory and the
 stream; every computation below happens in libivae_amd.so's HIP kernels."""
+import contextlib
 import ctypes as C
 import math
 from dataclasses import dataclass
@@ -329,7 +330,8 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
             raise ValueError("eps must be (n_models, n_steps, batch, latent_dim)")
     dims = shape.dims(B, n_models)
     dev = params.device
-    with torch.cuda.device(dev):
+    # (a device guard only when the caller's current device is another one: entering it costs microseconds per launch)
+    with (torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else contextlib.nullcontext()):
         loss = torch.empty(n_models, n_steps, dtype=torch.float32, device=dev)
         z = torch.empty(n_models, B, shape.latent_dim, dtype=torch.float32, device=dev) if want_z else None
         zs = (torch.empty(n_models, n_steps, B, shape.latent_dim, dtype=torch.float32, device=dev)

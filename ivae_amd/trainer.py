@@ -165,6 +165,19 @@ class FusedPackedTrainer:
         self._perm = torch.rand(self.M, N, generator=self.gen, device=self.dev).argsort(1).to(torch.int32)
         self._cursor = 0
 
+    def prepare_timing(self, n_launches):
+        """Create the HIP events of the next `n_launches` timed launches now (an event is created by the driver at its
+        first record: ~10 us each that would otherwise sit between the launches being timed)."""
+        pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_launches)]
+        for e in pool:
+            e.record()
+        torch.cuda.synchronize(self.dev)
+        self._ev_pool = pool
+
+    def _event(self):
+        pool = getattr(self, "_ev_pool", None)
+        return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+
     def run(self, n_steps, timed=False, want_z=False):
         """Advance all models by n_steps; returns the (n_models, n_steps) loss tensor (device)."""
         out, z = [], None
@@ -174,7 +187,7 @@ class FusedPackedTrainer:
             k = min(n_steps, self.CHUNK, self._nb - self._cursor)
             idx = self._perm[:, self._cursor * self.B:(self._cursor + k) * self.B].reshape(self.M, k, self.B).contiguous()
             if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = self._event(), self._event()
                 e0.record()
             loss, z = ops.train_steps(self.shape, self.coef, self.params, self.exp_avg, self.exp_avg_sq, self.x, self.u,
                                       idx, self.t, self.lr, seed=self.seed, want_z=want_z and k == n_steps)
