@@ -258,9 +258,9 @@ def main():
     t0 = time.perf_counter()
     advance(args.steps, True)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0          # this rank's K steps; the MAX over ranks below is the job's time
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

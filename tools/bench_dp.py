@@ -77,9 +77,9 @@ def main():
     t0 = time.perf_counter()
     loss = run(args.steps)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0          # this rank's time; the MAX over ranks below is the job's
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
