@@ -1065,23 +1065,29 @@ __global__ __launch_bounds__(64 * CH_NW * 3) __attribute__((amdgpu_waves_per_eu(
     B.row0 = row0; B.nrows = nrows; B.TR = TR; B.np = L.n_params; B.d0 = t0; B.d1 = t1;
     float* fm = wsm + L.ws.f + (size_t)row0 * L.dd;
     MSTAMP(302);
-    if (grp == 0) {
-        // (the hidden tiles still hold the g chain's activations: every column a product reads is rewritten by the
+    // The decoder of a two-row-tile workgroup runs as TWO groups, one row tile each (the g and the logv group, on their own
+    // tiles): the groups that only kept step through the decoder's barriers were a third of this kernel's wave cycles.
+    constexpr int DRT = RTE == 2 ? 1 : RTE;            // row tiles a decoder group works on
+    const int ndg = RTE == 2 ? 2 : 1;                  // decoder groups
+    const int ro = RTE == 2 ? 16 * grp : 0;            // first tile row of my decoder group
+    const int nrd = RTE == 2 ? max(0, min(16, nrows - ro)) : nrows;
+    if (grp < ndg) {
+        // (the hidden tiles still hold the encoder chain's activations: every column a product reads is rewritten by the
         // previous one, the constant-1 column stays)
         FwdCtx X;
-        X.P = P; X.wsm = wsm; X.row0 = row0; X.nrows = nrows; X.h0 = t0; X.h1 = t1;
+        X.P = P; X.wsm = wsm; X.row0 = row0 + ro; X.nrows = nrd; X.h0 = t0; X.h1 = t1;
         auto head = [&](int rt, int col0, const f32x4& acc, const f32x4&) {
             const int n = col0 + c;
             if (n < L.dd) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = 16 * rt + 4 * q + r;
+                    const int row = ro + 16 * rt + 4 * q + r;
                     sf[row * ldf + n] = acc[r];
                     if (row < nrows) fm[(size_t)row * L.dd + n] = acc[r];
                 }
             }
         };
-        mlp_fwd<RTE, NW>(L, X, DF, sz, lds, false, St, head);
+        mlp_fwd<DRT, NW>(L, X, DF, sz + ro * lds, lds, false, St, head);
     } else {
         for (int li = 0; li < L.L; ++li) __syncthreads();
     }
@@ -1123,19 +1129,22 @@ __global__ __launch_bounds__(64 * CH_NW * 3) __attribute__((amdgpu_waves_per_eu(
     // ---- decoder input-gradient chain (group 0): layer deltas of f -> workspace, dLoss/dz -> sdz
     const float w = 1.f / (float)C.global_batch;
     {
-        // dLoss/df = -a*w*(x-f)/var, all TR rows (zero beyond the batch), over group 0's first tile (dead activations)
-        float* dF = tiles;
+        // dLoss/df = -a*w*(x-f)/var, all TR rows (zero beyond the batch), over the first tile of the decoder group that
+        // owns the row (dead activations)
         float* dltF = wsm + DF.lay[L.L - 1].dlt_off + row0;
         for (int idx = tid; idx < TR * L.dd; idx += NT) {
             const int r = idx / L.dd, k = idx - r * L.dd;
             const float v = r < nrows ? -C.a * w * (xin[r * L.ldx + k] - sf[r * ldf + k]) / C.decoder_var : 0.f;
-            dF[r * L.ldd + k] = v;
+            const int dg = RTE == 2 ? r >> 4 : 0;
+            tiles[dg * 2 * TR * ldt + (r - (RTE == 2 ? 16 * dg : 0)) * L.ldd + k] = v;
             dltF[(size_t)k * L.Bp + r] = v;
         }
     }
     MSTAMP(305);
-    if (grp == 0) {
-        mlp_bwd<RTE, NW>(L, B, DF, sdz, lds, St);
+    if (grp < ndg) {
+        BwdCtx Bd = B;
+        Bd.row0 = row0 + ro; Bd.nrows = nrd;
+        mlp_bwd<DRT, NW>(L, Bd, DF, sdz + ro * lds, lds, St);
     } else {
         for (int li = 0; li < L.L; ++li) __syncthreads();
     }
