@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // buffer of their own; no output depends on them and the shipped library contains none.
 #ifdef FT_PROF
 __device__ unsigned long long* g_ft_prof = nullptr;
-#define FT_NSTAMP 64
+#define FT_NSTAMP 128
 #define STAMP(i)                                                                                   \
     do {                                                                                           \
         if (blockIdx.x == 0 && threadIdx.x == 0 && g_ft_prof) {                                    \
@@ -54,9 +54,19 @@ __device__ unsigned long long* g_ft_prof = nullptr;
             g_ft_prof[(size_t)s * FT_NSTAMP + 32 + (threadIdx.x >> 4) + (i)] = t_;                 \
         }                                                                                          \
     } while (0)
+// backward-phase stamps of wave 0 (slots 64+i) and wave 4 (slots 96+i), i < 32
+#define STAMPB(i)                                                                                  \
+    do {                                                                                           \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256) && g_ft_prof) {            \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            g_ft_prof[(size_t)s * FT_NSTAMP + 64 + (threadIdx.x >> 3) + (i)] = t_;                 \
+        }                                                                                          \
+    } while (0)
 #else
 #define STAMP(i)
 #define STAMPW(i)
+#define STAMPB(i)
 #endif
 
 #define FT_THREADS 512
@@ -1079,16 +1089,24 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             const float t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
             A.loss_out[(size_t)model * A.n_steps_total + A.step_begin + s] = -t * wB;
         }
+        STAMPB(0);
         dgrad_hidden<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), T2, T0, slope, w);
+        STAMPB(1);
         if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
+        STAMPB(2);
         BAR(13);
         // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
-        stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), T4, T2, slope, w); },
-                LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_G2, sZ); });
+        STAMPB(3);
+        stagger(w, LAMBDA { STAMPB(4); dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), T4, T2, slope, w); STAMPB(5); },
+                LAMBDA { STAMPB(6); wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); STAMPB(7); ADAM(L_G2, sZ); STAMPB(8); });
+        STAMPB(9);
         BAR(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
+        STAMPB(10);
         WGRAD_ADAM(H, KS_E0, C::KIN, T2, ST, T3, ST, T0, L_G1, T1);
+        STAMPB(11);
         if (w >= 4) restore_rows<C>(s2, T4, rt);
+        STAMPB(12);
         BAR(15);
 
         // ---- V3: d2v -> T1; head gradient -> sZ; Adam(G0); h1v -> T2

@@ -425,6 +425,164 @@ def make_runner_traces():
     np.savez_compressed(os.path.join(OUT, "trace_runner.npz"), **out)
 
 
+# ---- full-length family-A runs (configs/ivae.yaml:29, btcvae.yaml: 20 epochs = 12 500 steps) -------------------------
+FULL_CASES = {
+    # name: yaml file of the reference, config overrides, epochs
+    "ivae": ("ivae.yaml", {}, 20),
+    "btcvae": ("btcvae.yaml", {}, 20),
+}
+FULL_SEEDS = (0, 1, 2, 3)
+FULL_TWINS = (1, 2)
+
+
+def order_seed(seed):
+    """Seed of the generator the DataLoader of a full-length run shuffles with (a shim passes it: the row order of every
+    epoch then follows from this number, and the fixture need not hold 20 x 40 000 indices per run)."""
+    return 5_000_000 + seed
+
+
+def epoch_orders(seed, N, B, epochs):
+    """Row order of each epoch of a full-length run: what torch's DataLoader(shuffle=True, drop_last=True,
+    generator=manual_seed(order_seed(seed))) asks its dataset for, epoch after epoch (tests/ rebuild it the same way)."""
+    from torch.utils.data import DataLoader
+
+    class Rows(torch.utils.data.Dataset):
+        def __len__(self):
+            return N
+
+        def __getitem__(self, i):
+            return i
+
+    dl = DataLoader(Rows(), batch_size=B, shuffle=True, drop_last=True, generator=torch.Generator().manual_seed(order_seed(seed)))
+    return [torch.cat([b for b in dl]) for _ in range(epochs)]
+
+
+def order_digest(rows):
+    """A few numbers that pin an epoch's row order (first rows and a position-weighted sum)."""
+    r = np.asarray(rows, np.int64)
+    return np.array([r[0], r[1], r[2], r[-1], int((r * (np.arange(r.size) % 1009 + 1)).sum() % (2 ** 53))], np.int64)
+
+
+def make_full_trace(name, seed):
+    """One full-length run of the reference's `runner` (runners/ivae.py:13-128, all 20 epochs of the yaml config) plus
+    FULL_TWINS runs of the same with the initial parameters moved by 1e-6 relative -> tests/golden/_full/<name>.s<seed>.npz.
+    Same recording shims as make_runner_traces, plus one: the DataLoader is given generator=manual_seed(order_seed(seed))."""
+    import argparse
+    import tempfile
+    import yaml
+    from torch.utils.data import DataLoader
+    torch.set_num_threads(1)
+    if not hasattr(np, "int"):
+        np.int = int
+    import runners.ivae as R
+    yml, over, epochs = FULL_CASES[name]
+    rec = argparse.Namespace()
+
+    class RecDataset(R.SyntheticDataset):
+        def __getitem__(self, index):
+            rec.order.append(int(index))
+            return super().__getitem__(index)
+
+    def recording(base):
+        class Rec(base):
+            def __init__(self, *a, **kw):
+                super().__init__(*a, **kw)
+                if rec.perturb:
+                    gen = torch.Generator().manual_seed(4242 + rec.perturb)
+                    with torch.no_grad():
+                        for p in self.parameters():
+                            p.mul_(1 + 1e-6 * torch.randn(p.shape, generator=gen))
+
+            def elbo(self, x, u, N, a=1., b=1., c=1., d=1.):
+                torch.manual_seed(noise_seed(rec.seed, rec.step))
+                loss, z = super().elbo(x, u, N, a=a, b=b, c=c, d=d)
+                rec.losses.append(float(loss.item()))
+                rec.coefs.append((a, b, c, d))
+                rec.step += 1
+                return loss, z
+
+            def forward(self, x, *rest):
+                if x.shape[0] == rec.N:
+                    torch.manual_seed(eval_seed(rec.seed))
+                return super().forward(x, *rest)
+        return Rec
+
+    class RecPlateau(torch.optim.lr_scheduler.ReduceLROnPlateau):
+        def __init__(self, optimizer, *a, verbose=None, **kw):
+            super().__init__(optimizer, *a, **kw)
+
+        def step(self, metrics, *a, **kw):
+            super().step(metrics, *a, **kw)
+            rec.lrs.append(self.optimizer.param_groups[0]["lr"])
+
+    def seeded_loader(dset, **kw):
+        return DataLoader(dset, generator=torch.Generator().manual_seed(order_seed(rec.seed)), **kw)
+
+    R.SyntheticDataset, R.cleanIVAE, R.cleanVAE, R.DataLoader = RecDataset, recording(R.cleanIVAE), recording(R.cleanVAE), seeded_loader
+    torch.optim.lr_scheduler.ReduceLROnPlateau = RecPlateau
+    with open(os.path.join(REF, "configs", yml)) as f:
+        cfg = yaml.safe_load(f)
+    cfg.update(over)
+    cfg["epochs"] = epochs
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        config = argparse.Namespace(**cfg)
+        config.device = torch.device("cpu")
+        args = argparse.Namespace(data_path=tmp + "/", seed=seed, n_sims=1)
+
+        def run(perturb):
+            rec.seed, rec.step, rec.N, rec.perturb = seed, 0, cfg["nps"] * cfg["ns"], perturb
+            rec.order, rec.losses, rec.coefs, rec.lrs = [], [], [], []
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+            return R.runner(args, config)
+
+        key = f"{name}.s{seed}"
+        perfs, loss_hists, perf_hists = run(0)
+        B = cfg["batch_size"]
+        nb = rec.N // B
+        assert len(rec.order) == epochs * nb * B and len(rec.losses) == epochs * nb
+        rebuilt = torch.cat(epoch_orders(seed, rec.N, B, epochs)).numpy()
+        assert np.array_equal(rebuilt, np.array(rec.order)), "epoch_orders does not reproduce the DataLoader's order"
+        out[key + ".order_digest"] = np.stack([order_digest(rec.order[e * nb * B:(e + 1) * nb * B]) for e in range(epochs)])
+        out[key + ".first_epoch_step_loss"] = np.array(rec.losses[:nb], np.float32)
+        out[key + ".step_coef"] = np.array(rec.coefs[::nb], np.float32)
+        out[key + ".lr"] = np.array(rec.lrs, np.float64)
+        out[key + ".loss_hist"] = np.array(loss_hists[0], np.float64)
+        out[key + ".perf_hist"] = np.array(perf_hists[0], np.float64)
+        out[key + ".perf"] = np.array(perfs[0], np.float64)
+        print(f"full trace {key}: loss {loss_hists[0][0]:.3f} -> {loss_hists[0][-1]:.3f} perf_hist {perf_hists[0][-1]:.4f} "
+              f"lr {rec.lrs} full perf {perfs[0]:.4f}", flush=True)
+        sens = []
+        for k in FULL_TWINS:
+            r_ = run(k)
+            sens.append((r_, list(rec.lrs)))
+            print(f"  twin {k} of {key}: perf {r_[0][0]:.4f} lr {rec.lrs}", flush=True)
+        out[key + ".sens_loss_hist"] = np.array([r_[1][0] for r_, _ in sens], np.float64)
+        out[key + ".sens_perf_hist"] = np.array([r_[2][0] for r_, _ in sens], np.float64)
+        out[key + ".sens_perf"] = np.array([r_[0][0] for r_, _ in sens], np.float64)
+        out[key + ".sens_lr"] = np.array([l for _, l in sens], np.float64)
+        out[key + ".config"] = np.array(json.dumps(dict(key=key, name=name, seed=seed, epochs=epochs, config=cfg)))
+    os.makedirs(os.path.join(OUT, "_full"), exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "_full", key + ".npz"), **out)
+
+
+def merge_full_traces():
+    """tests/golden/_full/*.npz -> tests/golden/trace_full.npz (one index entry per run)."""
+    out, index = {}, []
+    d = os.path.join(OUT, "_full")
+    for fn in sorted(os.listdir(d)):
+        g = np.load(os.path.join(d, fn))
+        for k in g.files:
+            if k.endswith(".config"):
+                index.append(json.loads(str(g[k])))
+            else:
+                out[k] = g[k]
+    out["index"] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, "trace_full.npz"), **out)
+    print("merged", len(index), "runs")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "runner_traces":
@@ -435,6 +593,10 @@ def main():
         return make_traces()
     if len(sys.argv) > 1 and sys.argv[1] == "trace_twins":
         return make_trace_twins()
+    if len(sys.argv) > 1 and sys.argv[1] == "full_trace":          # full_trace <ivae|btcvae> <seed>
+        return make_full_trace(sys.argv[2], int(sys.argv[3]))
+    if len(sys.argv) > 1 and sys.argv[1] == "full_merge":
+        return merge_full_traces()
     # family B (models/nets.py:391-486, 548-599)
     make_case("ivae_plain_tiny", "iVAE", (3, 3, 4), B=5, H=8)
     make_case("ivae_plain_cfg2", "iVAE", (10, 10, 40), B=64, H=50)

@@ -29,11 +29,12 @@ u = torch.zeros(M, 4000, 40, device=dev)
 u[:, torch.arange(4000), torch.arange(4000) % 40] = 1
 tr.set_data(x, u)
 tr.run(8)
-buf = torch.zeros(steps * 64, dtype=torch.int64, device=dev)
+NST = 128
+buf = torch.zeros(steps * NST, dtype=torch.int64, device=dev)
 assert _lib.lib().ivae_debug_set_prof(C.c_void_p(buf.data_ptr())) == 0
 tr.run(steps)
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(steps, 64)[:, :NSEG].astype(np.float64)
+t = buf.cpu().numpy().reshape(steps, NST)[:, :NSEG].astype(np.float64)
 seg = np.diff(np.concatenate([t[:-1], t[1:, :1]], 1), axis=1)[4:]      # (steps-1, 34) cycles per segment
 mean = seg.mean(0)
 tot = mean.sum()
@@ -42,7 +43,7 @@ for l, c in zip(LABELS, mean):
     print(f"  {l:28s} {c:9.0f}  {100*c/tot:5.1f}%")
 # forward-stage timeline of wave 0 (g chain, decoder; slots 32..) and wave 4 (logv chain, prior; slots 48..), cycles from
 # the stage's first stamp of wave 0
-raw = buf.cpu().numpy().reshape(steps, 64).astype(np.float64)[6:]
+raw = buf.cpu().numpy().reshape(steps, NST).astype(np.float64)[6:]
 names0 = ["start", "g L0", "g L1", "g head", "wait v", "z", "dec L0", "dec L1", "dec head+dO"]
 names4 = ["start", "v L0", "v L1", "v head", "prior L0", "prior L1 (+wait g)", "prior head", "wait z"]
 for wv, base, names in (("wave0", 32, names0), ("wave4", 48, names4)):
@@ -51,3 +52,11 @@ for wv, base, names in (("wave0", 32, names0), ("wave4", 48, names4)):
     print(wv, " ".join(f"{n}@{int(v)}(+{int(v - (m[i - 1] if i else 0))})" for i, (n, v) in enumerate(zip(names, m))))
 print("wave0 g L1: product took", int((raw[:, 32 + 9] - raw[:, 32 + 1]).mean()), "epilogue", int((raw[:, 32 + 2] - raw[:, 32 + 9]).mean()))
 print("stage barrier released (STAMP 8) @", int((raw[:, 8] - raw[:, 32]).mean()))
+
+# backward stamps of G3 / G2 / G1, waves 0 and 4, cycles since the phase's barrier release on wave 0
+for wv, base in (("wave0", 64), ("wave4", 96)):
+    def rel(i, ref):
+        return int((raw[:, base + i] - raw[:, ref]).mean())
+    print(wv, "G3: start", rel(0, 12), "dgrad done", rel(1, 12), "wgrad_tile done", rel(2, 12), "| barrier13 @", int((raw[:, 13] - raw[:, 12]).mean()))
+    print(wv, "G2: start", rel(3, 13), "matrix half", rel(4, 13), "->", rel(5, 13), " vector half wgrad", rel(6, 13), "->", rel(7, 13), "adam ->", rel(8, 13), "end", rel(9, 13), "| barrier14 @", int((raw[:, 14] - raw[:, 13]).mean()))
+    print(wv, "G1: start", rel(10, 14), "wgrad+adam done", rel(11, 14), "restore done", rel(12, 14), "| barrier15 @", int((raw[:, 15] - raw[:, 14]).mean()))
