@@ -16,12 +16,13 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 $(LIB): $(OBJS)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
-# diagnostic build with in-kernel phase stamps (never shipped, never benchmarked)
-prof: ivae_amd/libivae_amd_prof.so
-ivae_amd/libivae_amd_prof.so: $(SRCS) $(HDRS)
-	$(HIPCC) $(CXXFLAGS) -DFT_PROF -shared $(SRCS) -o $@
+# diagnostic build with in-kernel phase stamps: another library name, -DIVAE_DIAG (the sources refuse their diagnostic
+# switches without it; ivae_version() says so) -- never shipped, never benchmarked
+diag: ivae_amd/libivae_amd_diag.so
+ivae_amd/libivae_amd_diag.so: $(SRCS) $(HDRS)
+	$(HIPCC) $(CXXFLAGS) -DIVAE_DIAG -DFT_PROF $(DIAGFLAGS) -shared $(SRCS) -o $@
 
 clean:
 	rm -f $(OBJS) $(LIB)
 
-.PHONY: all clean
+.PHONY: all clean diag

@@ -172,14 +172,19 @@ int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef,
  *   z_out (n_models, 64, latent_dim) of the LAST step, or NULL;
  *   z_steps (n_models, n_steps, 64, latent_dim) of EVERY step (the per-step z_est that
  *   models/wrappers.py:75 scores against the true sources), or NULL.
- * coef: a, b, d, decoder_var are used (pairwise must be 0, global_batch 64). */
+ * coef: a, b, d, decoder_var are used (pairwise must be 0, global_batch 64).
+ * model_lr: NULL, or n_models learning rates in HOST memory, read before the call returns: model m trains with
+ *   model_lr[m] instead of `lr` (every packed run has its own ReduceLROnPlateau, runners/ivae.py:39,113-114;
+ *   models/wrappers.py:45,83); `lr` must then be non-zero (the step table is formed for it, a model's rate is a factor).
+ * A hand-off between the waves of a model that times out inside the kernel (a protocol error, never seen) turns that
+ * model's losses into NaN from that step on: check loss_out before trusting the parameters. */
 int ivae_train_steps_supported(const IvaeDims* dims);
 int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef,
                      float* params, float* exp_avg, float* exp_avg_sq,
                      const float* x_data, const float* u_data, int64_t n_data,
                      const int32_t* batch_idx, const float* eps, uint64_t seed,
                      int32_t n_steps, int64_t step0,
-                     double lr, double beta1, double beta2, double adam_eps,
+                     double lr, const double* model_lr, double beta1, double beta2, double adam_eps,
                      float* loss_out, float* z_out, float* z_steps, void* stream);
 
 /* ---- Adam ---------------------------------------------------------------------------
@@ -221,6 +226,9 @@ int ivae_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t 
 /* ---- diagnostics ---------------------------------------------------------------------- */
 const char* ivae_last_hip_error(void);   /* text of the last failing HIP call (thread-local) */
 const char* ivae_version(void);
+/* Test hook, no counterpart in the reference: bit 0 makes ivae_train_steps's kernel skip one hand-off between the waves
+ * of a model, so that the time-out report above can be exercised (tests/test_gpu_fused.py).  0 = normal operation. */
+int ivae_debug_fault_inject(int32_t mask);
 
 #ifdef __cplusplus
 }

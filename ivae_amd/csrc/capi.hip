@@ -18,7 +18,11 @@ static int hip_fail(hipError_t e, const char* where) {
 extern "C" {
 
 const char* ivae_last_hip_error(void) { return g_err; }
-const char* ivae_version(void) { return "ivae_amd 0.1 (gfx950)"; }
+#ifdef IVAE_DIAG
+const char* ivae_version(void) { return "ivae_amd 0.3 (gfx950) DIAG build: timing switches and stamps, results may be wrong"; }
+#else
+const char* ivae_version(void) { return "ivae_amd 0.3 (gfx950)"; }
+#endif
 
 int ivae_param_count(const IvaeDims* dims, int64_t* out) {
     if (!out) return IVAE_E_NULLPTR;
@@ -196,10 +200,18 @@ int ivae_train_steps_supported(const IvaeDims* d) {
     return fused_supported(d->data_dim, d->latent_dim, d->aux_dim, d->hidden_dim, d->n_layers, d->activation, d->batch) ? 1 : 0;
 }
 
+static int g_fault = 0;       // ivae_debug_fault_inject
+
+int ivae_debug_fault_inject(int32_t mask) {
+    g_fault = mask;
+    return IVAE_OK;
+}
+
 int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
                      const float* x_data, const float* u_data, int64_t n_data, const int32_t* batch_idx,
-                     const float* eps, uint64_t seed, int32_t n_steps, int64_t step0, double lr, double beta1,
-                     double beta2, double adam_eps, float* loss_out, float* z_out, float* z_steps, void* stream) {
+                     const float* eps, uint64_t seed, int32_t n_steps, int64_t step0, double lr, const double* model_lr,
+                     double beta1, double beta2, double adam_eps, float* loss_out, float* z_out, float* z_steps,
+                     void* stream) {
     int rc = ivae_check_dims(dims);
     if (rc) return rc;
     if ((rc = check_coef(dims, coef))) return rc;
@@ -208,25 +220,46 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, 
         return IVAE_E_NULLPTR;
     if (n_steps <= 0 || n_data <= 0 || step0 < 0) return IVAE_E_BADDIMS;
     if (n_data > 0x7fffffff) return IVAE_E_TOOLARGE;          // row indices are int32
+    if (model_lr) {           // the step table is formed for `lr`; a model's own rate enters as a factor on it
+        if (!(lr != 0.0)) return IVAE_E_BADDIMS;
+    }
+    int64_t P = 0;
+    if ((rc = ivae_param_count(dims, &P))) return rc;
+    const size_t dd = dims->data_dim, dl = dims->latent_dim, da = dims->aux_dim;
     FusedArgs A;
-    A.params = params; A.exp_avg = exp_avg; A.exp_avg_sq = exp_avg_sq;
-    A.x_data = x_data; A.u_data = u_data; A.batch_idx = batch_idx; A.eps = eps;
-    A.loss_out = loss_out; A.z_steps = z_steps; A.n_data = n_data; A.seed = seed;
+    A.n_data = n_data; A.seed = seed;
     A.a = coef->a; A.b = coef->b; A.d = coef->d; A.decoder_var = coef->decoder_var; A.slope = dims->slope;
     A.w1 = (float)(1.0 - beta1); A.beta2 = (float)beta2; A.w2 = (float)(1.0 - beta2); A.adam_eps = (float)adam_eps;
     A.n_steps_total = n_steps;
+    A.fault = g_fault;
     for (int begin = 0; begin < n_steps; begin += FT_MAX_STEPS) {
         const int n = n_steps - begin < FT_MAX_STEPS ? n_steps - begin : FT_MAX_STEPS;
         A.n_steps = n; A.step_begin = begin; A.step0 = step0 + begin;
-        A.z_out = begin + n == n_steps ? z_out : nullptr;
         for (int s = 0; s < n; ++s) {
             const double t = (double)(step0 + begin + s + 1);
             A.neg_step[s] = (float)(-lr / (1.0 - pow(beta1, t)));
             A.inv_bc2_sqrt[s] = (float)(1.0 / sqrt(1.0 - pow(beta2, t)));
         }
-        hipError_t e = launch_train_steps(dims->data_dim, dims->latent_dim, dims->aux_dim, dims->hidden_dim, A,
-                                          dims->n_models, (hipStream_t)stream);
-        if (e != hipSuccess) return hip_fail(e, "ivae_train_steps");
+        // a launch carries the per-model rate factors of at most FT_MAX_MODELS models: longer packs go in slices (every
+        // per-model array advances by its own stride; the kernel numbers a slice's models from 0)
+        for (int m0 = 0; m0 < dims->n_models; m0 += FT_MAX_MODELS) {
+            const int nm = dims->n_models - m0 < FT_MAX_MODELS ? dims->n_models - m0 : FT_MAX_MODELS;
+            const size_t m = (size_t)m0;
+            A.params = params + m * P; A.exp_avg = exp_avg + m * P; A.exp_avg_sq = exp_avg_sq + m * P;
+            A.x_data = x_data + m * n_data * dd;
+            A.u_data = u_data ? u_data + m * n_data * da : nullptr;
+            A.batch_idx = batch_idx + m * n_steps * 64;
+            A.eps = eps ? eps + m * n_steps * 64 * dl : nullptr;
+            A.loss_out = loss_out + m * n_steps;
+            A.z_steps = z_steps ? z_steps + m * n_steps * 64 * dl : nullptr;
+            A.z_out = (begin + n == n_steps && z_out) ? z_out + m * 64 * dl : nullptr;
+            A.model0 = m0;
+            for (int i = 0; i < nm; ++i) A.lr_scale[i] = model_lr ? (float)(model_lr[m0 + i] / lr) : 1.f;
+            for (int i = nm; i < FT_MAX_MODELS; ++i) A.lr_scale[i] = 1.f;
+            hipError_t e = launch_train_steps(dims->data_dim, dims->latent_dim, dims->aux_dim, dims->hidden_dim, A, nm,
+                                              (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "ivae_train_steps");
+        }
     }
     return IVAE_OK;
 }

@@ -28,6 +28,10 @@
 // Reference arithmetic restated here: models/nets.py:114-121 (MLP.forward), 301-314 (Normal.sample / log_pdf),
 // 45-52 (log_normal), 450-475, 587-599, 165-185, 224-243 (forward / elbo of the four model classes); backward =
 // what autograd derives from those (SURVEY.md §8 a-bwd).
+#if !defined(IVAE_DIAG) && (defined(MF_PROF) || defined(MF_PROF_FINE) || defined(MF_WARM_ARGS) || defined(MF_TRANSPARENT) || \
+                            defined(MF_FULL_BARRIER) || defined(WG_PD) || defined(WG_OCC) || defined(CH_NW) || defined(CH_OCC))
+#error "MF_* / WG_* / CH_* are switches of the diagnostic build (make diag, -DIVAE_DIAG): never into libivae_amd.so"
+#endif
 #include <hip/hip_runtime.h>
 #include "layout.h"
 #include "kernels.h"

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #define FT_MAX_STEPS 128
+#define FT_MAX_MODELS 256     // models per launch (a longer pack is launched in slices)
 
 struct FusedArgs {
     float* params;            // (n_models, P) in/out
@@ -26,6 +27,9 @@ struct FusedArgs {
     float w1, beta2, w2, adam_eps;      // 1-beta1, beta2, 1-beta2, eps
     float neg_step[FT_MAX_STEPS];       // -lr / (1 - beta1^t)
     float inv_bc2_sqrt[FT_MAX_STEPS];   // 1 / sqrt(1 - beta2^t)
+    float lr_scale[FT_MAX_MODELS];      // model_lr[m] / lr (1 when the pack shares one learning rate)
+    int model0;                         // number of this launch's first model inside the pack (Philox stream id)
+    int fault;                          // fault injection for tests (ivae_debug_fault_inject); 0 in normal use
 };
 
 bool fused_supported(int dd, int dl, int m, int h, int n_layers, int act, int batch);

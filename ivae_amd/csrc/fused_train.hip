@@ -32,8 +32,12 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Diagnostic build only (make prof): s_memtime stamps at phase boundaries of model 0 / wave 0 go to a
-// buffer of their own; no output depends on them and the shipped library contains none.
+// Diagnostic build only (make diag: -DIVAE_DIAG -DFT_PROF, a library of another name): s_memtime stamps at phase
+// boundaries of model 0 / waves 0 and 4 go to a buffer of their own; no output depends on them and the shipped
+// library contains none.
+#if defined(FT_PROF) && !defined(IVAE_DIAG)
+#error "FT_PROF belongs to the diagnostic build (make diag, -DIVAE_DIAG): never into libivae_amd.so"
+#endif
 #ifdef FT_PROF
 __device__ unsigned long long* g_ft_prof = nullptr;
 #define FT_NSTAMP 128
@@ -125,9 +129,7 @@ struct FCfg {
 // addresses out of the step loop (dozens of phases x several VGPRs each -> spills).
 __device__ __forceinline__ int opaque_lane() {
     int l = threadIdx.x & 63;
-#ifndef FT_TRANSPARENT_LANE
     asm volatile("" : "+v"(l));
-#endif
     return l;
 }
 
@@ -135,36 +137,14 @@ __device__ __forceinline__ int opaque_lane() {
 // step loop go through LDS; __syncthreads() would also drain vmcnt and so expose the latency of the
 // next batch's prefetch (global loads into registers that nothing reads until the next step).
 __device__ __forceinline__ void lds_barrier() {
-#ifdef FT_ABL_NOBARRIER       // timing experiment only (results are wrong)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-#ifdef FT_ABL_NOMFMA          // timing experiment only: one VALU op in place of the matrix instruction
-    c[0] += a * b;
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
 }
-__device__ __forceinline__ f32x2 ld2(const float* p) {
-#ifdef FT_ABL_NOLDS           // timing experiment only: operand registers left undefined instead of read from LDS
-    f32x2 r;
-    asm volatile("" : "=v"(r) : "v"(p));
-    return r;
-#else
-    return *reinterpret_cast<const f32x2*>(p);
-#endif
-}
-__device__ __forceinline__ void st2(float* p, float a, float b) {
-#ifdef FT_ABL_NOSTORE         // timing experiment only: results computed, (almost) never stored
-    if (a != 1.2345e30f) return;
-#endif
-    *reinterpret_cast<f32x2*>(p) = (f32x2){a, b};
-}
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ void st2(float* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = (f32x2){a, b}; }
 // leaky ReLU for 0 <= slope <= 1 (checked on the host before launch): max(p, slope * p)
 __device__ __forceinline__ float lrelu(float p, float slope) { return fmaxf(p, p * slope); }
 
@@ -174,13 +154,8 @@ __device__ __forceinline__ float flog(float x) { return 0.6931471805599453f * __
 // e^x on the hardware exp2 unit (v_exp_f32, 1 ulp in exp2; the argument's rounding adds |x| * 6e-8 relative)
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(1.4426950408889634f * x); }
 
-// Workgroup barrier number n of the step (diagnostic builds: -DFT_SKIP_BAR=n leaves that one out -- timing experiment
-// only, the results are wrong -- to see what each barrier costs).
-#ifdef FT_SKIP_BAR
-#define BAR(n) do { if ((n) != FT_SKIP_BAR) lds_barrier(); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(n); } while (0)
-#else
+// Workgroup barrier number n of the step (the diagnostic build stamps its release).
 #define BAR(n) do { lds_barrier(); STAMP(n); } while (0)
-#endif
 
 #define ZERO4 ((f32x4){0.f, 0.f, 0.f, 0.f})
 // LDS offsets are far below 2^23: full-rate 24-bit multiply instead of the quarter-rate v_mul_lo_u32
@@ -240,8 +215,15 @@ __device__ __forceinline__ void mm_fwd(const float* xrow, const float* const (&w
             a[t % R] = ld2(xrow + 8 * t + 2 * q);
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
+#if defined(IVAE_DIAG) && defined(FT_EXP_FWD_NOB)    // timing experiment (wrong results): no weight operand reads
+                asm volatile("" : "=v"(b[t % R][w][0]), "=v"(b[t % R][w][1]));
+#elif defined(IVAE_DIAG) && defined(FT_EXP_FWD_LINB) // timing experiment (wrong results): conflict-free weight reads
+                b[t % R][w][0] = ld2(wrow[0][0] - mul24(min(2 * (int)(threadIdx.x & 15), 49), KS) + 2 * (threadIdx.x & 63) + 128 * (2 * w) + 8 * t);
+                b[t % R][w][1] = ld2(wrow[0][0] - mul24(min(2 * (int)(threadIdx.x & 15), 49), KS) + 2 * (threadIdx.x & 63) + 128 * (2 * w + 1) + 8 * t);
+#else
                 b[t % R][w][0] = ld2(wrow[w][0] + 8 * t + 2 * q);
                 b[t % R][w][1] = ld2(wrow[w][1] + 8 * t + 2 * q);
+#endif
             }
         } else if (t == G) {
             at = xrow[8 * G + q];
@@ -379,6 +361,87 @@ __device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float*
     }
 }
 
+// mm_dgrad followed by mm_wgrad as ONE instruction stream: the weight-gradient product's first operands are requested
+// before the input-gradient product's last MFMAs, so the matrix pipe sees no gap between the two, and fill(t) -- the
+// input-gradient epilogue, which needs accd complete -- is issued between the weight-gradient MFMAs.
+template <int NS, int N, int KS, class F>
+__device__ __forceinline__ void mm_dgrad_wgrad(const float* yrow, const float* wcol, const float* ycol, int sy, const float* xcol,
+                                               int sx, int q, f32x4 (&accd)[2], f32x4 (&accw)[2], F&& fill) {
+    constexpr int G = (NS - 4) / 8, PF = FT_PF, R = PF + 1;
+    static_assert(NS == 8 * G + 4 && G >= 2, "contraction lengths are 4*odd, >= 20");
+    f32x2 a[R], b0[R], b1[R], bt = {0.f, 0.f};
+    float at = 0.f;
+#if defined(IVAE_DIAG) && defined(FT_EXP_LINEAR)     // timing experiment (wrong results): conflict-free operand addresses
+    const float* lin = (const float*)((size_t)yrow & ~(size_t)0xfff) + 2 * (threadIdx.x & 63);
+#endif
+    auto fetch = [&](int t) {
+        if (t < G) {
+            int n0 = 8 * t + 2 * q, n1 = n0 + 1;
+            if (8 * t + 7 >= N) { n0 = min(n0, N - 1); n1 = min(n1, N - 1); }
+#if defined(IVAE_DIAG) && defined(FT_EXP_LINEAR)
+            a[t % R] = ld2(lin + 384 * t); b0[t % R] = ld2(lin + 384 * t + 128); b1[t % R] = ld2(lin + 384 * t + 256);
+#elif defined(IVAE_DIAG) && defined(FT_EXP_NOLOAD)
+            asm volatile("" : "=v"(a[t % R]), "=v"(b0[t % R]), "=v"(b1[t % R]));
+#else
+            a[t % R] = ld2(yrow + 8 * t + 2 * q);
+            b0[t % R] = ld2(wcol + mul24(n0, KS));
+            b1[t % R] = ld2(wcol + mul24(n1, KS));
+#endif
+        } else if (t == G) {
+            int n = 8 * G + q;
+            if (8 * G + 3 >= N) n = min(n, N - 1);
+            at = yrow[8 * G + q];
+            bt = ld2(wcol + mul24(n, KS));
+        }
+    };
+    constexpr int WR = 3;
+    float wa[WR][2];
+    f32x2 wb[WR][2];
+    auto wfetch = [&](int t) {
+        if (t < WG_G) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#if defined(IVAE_DIAG) && defined(FT_EXP_LINEAR)
+                wa[t % WR][i] = lin[384 * t + 192 * i - (threadIdx.x & 63)]; wb[t % WR][i] = ld2(lin + 384 * t + 192 * i + 64);
+#elif defined(IVAE_DIAG) && defined(FT_EXP_NOLOAD)
+                asm volatile("" : "=v"(wa[t % WR][i]), "=v"(wb[t % WR][i]));
+#else
+                wa[t % WR][i] = ycol[(8 * t + 4 * i + q) * sy];
+                wb[t % WR][i] = ld2(xcol + (8 * t + 4 * i + q) * sx);
+#endif
+            }
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) fetch(t);
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const int cur = t % R;
+        fetch(t + PF);
+        if (t == G - 2) wfetch(0);
+        if (t == G - 1) wfetch(1);
+        SCHED_FENCE();
+        accd[0] = mfma4(a[cur].x, b0[cur].x, accd[0]);
+        accd[1] = mfma4(a[cur].x, b0[cur].y, accd[1]);
+        accd[0] = mfma4(a[cur].y, b1[cur].x, accd[0]);
+        accd[1] = mfma4(a[cur].y, b1[cur].y, accd[1]);
+        SCHED_FENCE();
+    }
+    accd[0] = mfma4(at, bt.x, accd[0]);
+    accd[1] = mfma4(at, bt.y, accd[1]);
+#pragma unroll
+    for (int t = 0; t < WG_G; ++t) {
+        const int cur = t % WR;
+        wfetch(t + 2);
+        SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { accw[0] = mfma4(wa[cur][i], wb[cur][i].x, accw[0]); accw[1] = mfma4(wa[cur][i], wb[cur][i].y, accw[1]); }
+        fill(t);
+        interleave_mfma<4, 5, 1>();
+        SCHED_FENCE();
+    }
+}
+
 // single tile: operands of all 16 k-steps read up front (32 registers)
 __device__ __forceinline__ f32x4 mm_wgrad1(const float* ycol, int sy, const float* xcol, int sx, int q) {
     float a[FT_B / 4], b[FT_B / 4];
@@ -489,12 +552,17 @@ __device__ __forceinline__ void flag_raise(float* flag, int step_no) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     *(lds_flag_t*)flag = step_no;
 }
-__device__ __forceinline__ void flag_wait(const float* flag, int step_no) {
+// A wait that runs out of polls (2^16 of them: tens of milliseconds, a thousand times the longest legitimate wait) raises
+// the model's error word; from that step on every loss the model reports is NaN (k_train_steps, loss out), so a missed
+// hand-off can never pass as a trained model.
+__device__ __forceinline__ void flag_wait(const float* flag, int step_no, float* err) {
+    bool seen = false;
 #pragma unroll 1
-    for (int spin = 0; spin < (1 << 18); ++spin) {
-        if (*(lds_flag_t*)flag >= step_no) break;
+    for (int spin = 0; spin < (1 << 16); ++spin) {
+        if (*(lds_flag_t*)flag >= step_no) { seen = true; break; }
         __builtin_amdgcn_s_sleep(FT_POLL_SLEEP);
     }
+    if (!seen) *(lds_flag_t*)err = 1;
     asm volatile("" ::: "memory");
 }
 
@@ -580,6 +648,41 @@ __device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float*
     for (int r = 0; r < 4; ++r) {
         const int n = 16 * nt + 4 * q + r;       // rows >= N land in the tail of the (64-row) stage tile unless guarded
         if (col0 < KS && (!ROWGUARD || n < N)) st2(stage + n * KS + col0, col0 <= KB ? acc[0][r] : 0.f, col0 + 1 <= KB ? acc[1][r] : 0.f);
+    }
+}
+
+// The middle phase of an MLP's backward pass as one stream per wave (wave w: rows 16*(w&3).., column half w>>2 of both
+// products): d1 = mask(h1) * (d2 W1) -> out, then the weight gradient of the same layer dW1 = d2^T [h1 | 1] -> stage.
+// The input-gradient epilogue (mask from h1, read before the first product) is issued between the weight-gradient MFMAs.
+template <class C, bool ROWGUARD>
+__device__ __forceinline__ void dgrad_wgrad_hidden(const float* dY, const float* W, const float* h, float* out, float* stage,
+                                                   float slope, int w) {
+    constexpr int ST = C::ST, KS = C::KS_H, H = C::H;
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
+    // lanes whose column pair lies past the tile write zeros to its last pair, as that pair's owner does (columns H, H + 1)
+    const int colw = min(col0, ST - 2);
+    static_assert(ST - 2 >= H, "the clamped column pair holds no product column");
+    const float* hrow = h + mul24(16 * rt + 4 * q, ST) + colw;
+    f32x2 hm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hm[r] = ld2(hrow + r * ST);
+    f32x4 accd[2] = {ZERO4, ZERO4}, accw[2] = {ZERO4, ZERO4};
+    const bool in0 = col0 < H, in1 = col0 + 1 < H;
+    float* orow = out + mul24(16 * rt + 4 * q, ST) + colw;
+    mm_dgrad_wgrad<KS, H, KS>(dY + mul24(16 * rt + c, ST), W + min(col0, KS - 2), dY + min(16 * rt + c, ST - 1), ST,
+                              h + min(col0, KS - 2), ST, q, accd, accw, [&](int t) __attribute__((always_inline)) {
+        if (t < 4) {
+            const float v0 = in0 ? accd[0][t] * (hm[t].x > 0.f ? 1.f : slope) : 0.f;
+            const float v1 = in1 ? accd[1][t] * (hm[t].y > 0.f ? 1.f : slope) : 0.f;
+            st2(orow + t * ST, v0, v1);
+        }
+    });
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = 16 * rt + 4 * q + r;       // rows >= H land in the tail of the (64-row) stage tile unless guarded
+        if (col0 < KS && (!ROWGUARD || n < H)) st2(stage + n * KS + col0, col0 <= H ? accw[0][r] : 0.f, col0 + 1 <= H ? accw[1][r] : 0.f);
     }
 }
 
@@ -781,14 +884,14 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     float* sZ = sL + C::SMALL;         // eps, then z (with its constant-1 column), then the head-gradient stage
     float* sO = sZ + C::SMALL;         // dLoss/df (decoder head delta), forward stage..BF3
     float* arena = sO + C::SMALL;      // parameters, last: anything read past the end of a tile is still a finite LDS word
-    float* sD = T1;                    // dLoss/dz from the decoder, BF1..E
-    float* stF0 = T1 + C::SMALL;       // gradient stage of the decoder's first layer, BF1..E
-    float* red = stF0 + C::H * C::KS_F0;   // 8 loss partials, E..G3
+    float* stF0 = T1 + C::SMALL;       // gradient stage of the decoder's first layer, BF1..G3
+    float* red = stF0 + C::H * C::KS_F0;   // 8 loss partials, BF1..G3
     // hand-off flags of the forward stage: pad column of T3, rows 0..11
     float* flagV = T3 + C::KIN + 1;                  // [rt]: v rows of tile rt are in sV, and T4's rows rt are free
     float* flagG = flagV + 4 * C::ST;                // [rt]: the g chain has read its last word of T0's rows rt
     float* flagZ = flagV + 8 * C::ST;                // [rt]: z rows of tile rt are in sZ
     float* flagL = flagV + 12 * C::ST;               // [rt]: h1l rows of tile rt are in T1
+    float* flagE = flagV + 16 * C::ST;               // error word: a hand-off wait timed out (sticky for the launch)
     static_assert(C::KIN + 1 < C::ST, "the input tile has a pad column for the flags");
 
     constexpr int ST = C::ST, SS = C::SS, H = C::H, DD = C::DD, DL = C::DL, M = C::M;
@@ -827,17 +930,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     if (tid < FT_B) T3[tid * ST + C::KIN] = 1.f;      // constant-1 (bias) column of the resident input tile
     __syncthreads();
 
-#if defined(FT_PRIO_X)
-    if (w_init < 4) __builtin_amdgcn_s_setprio(1);
-#elif defined(FT_PRIO_Y)
-    if (w_init >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     const float w1 = A.w1, b2 = A.beta2, w2 = A.w2, aeps = A.adam_eps;
     float xu[C::NXU];
     // row indices are clamped to the dataset: a bad index reads a wrong (valid) row instead of faulting the GPU
     const int last_row = (int)(A.n_data - 1);
     load_xu<C>(xu, min(max(idxp[tid >> 3], 0), last_row), xd, ud);
     float neg_step = 0.f, inv_bc2 = 1.f;       // of the previous step (its last layer's Adam runs in P0)
+    const float lr_scale = A.lr_scale[model];  // this model's learning rate relative to the table's (1: exact)
 
 // Weight-gradient product of one layer with Adam of another layer (LA, gradient in stage_a) issued between its MFMAs.
 #define WGRAD_ADAM(N_, KS_, KB_, DY_, SY_, X_, SX_, STAGE_, LA_, STAGE_A_)                                              \
@@ -851,11 +950,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         });                                                                                                            \
     } while (0)
 
-#ifdef FT_ABL_NOADAM           // timing experiment only
-#define ADAM(L_, STAGE_) ((void)0)
-#else
 #define ADAM(L_, STAGE_) adam_layer<C, L_>(arena, STAGE_, am, av, w1, b2, w2, neg_step, inv_bc2, aeps)
-#endif
 
     for (int s = 0; s < A.n_steps; ++s) {
         // wave id / lane re-derived per step behind an optimisation barrier so the address arithmetic of ~20
@@ -871,7 +966,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         if (s > 0) {
             if constexpr (C::HAS_U) ADAM(L_L0, T0); else ADAM(L_V0, T1);
         }
-        neg_step = A.neg_step[s];
+        neg_step = A.neg_step[s] * lr_scale;
         inv_bc2 = A.inv_bc2_sqrt[s];
         store_xu<C>(xu, T3);
         if (A.eps) {
@@ -881,7 +976,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             }
         } else if (tid * 4 < FT_B * DL) {
             float nrm[4];
-            philox_normal4(A.seed, (unsigned)tid, (unsigned)(A.step0 + s), (unsigned)model, 0x1234567u, nrm);
+            philox_normal4(A.seed, (unsigned)tid, (unsigned)(A.step0 + s), (unsigned)(A.model0 + model), 0x1234567u, nrm);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const int el = tid * 4 + i; sZ[(el / DL) * SS + el % DL] = nrm[i]; }
         }
@@ -900,12 +995,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         f32x4 s1[2][2], s2[2][2], s3[2][2];
         float lsum = 0.f;
         const int step_no = s + 1;
-#ifndef FT_ABL_NOXU            // timing experiment only: every step re-uses the first batch
         load_xu<C>(xu, next_row, xd, ud);                  // next batch's rows start to arrive in registers
-#endif
-#ifdef FT_ABL_NOFWD            // timing experiment only
-        if (A.n_steps < 0)
-#endif
         if (w < 4) {
             STAMPW(0);
             fwd_rows<C, KS_E0>(T3, ST, arena + C::off_of(L_G0), T0, slope, rt, s1);
@@ -924,7 +1014,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             if constexpr (C::HAS_U) flag_raise(flagG + rt * ST, step_no);          // T0's rows rt may be overwritten (h2l)
             fwd_head<C, DL, false>(T2, arena + C::off_of(L_G2), sG, rt);
             STAMPW(3);
-            flag_wait(flagV + rt * ST, step_no);
+            flag_wait(flagV + rt * ST, step_no, flagE);
             STAMPW(4);
 
             // reparameterisation z = g + eps * sqrt(v) (nets.py:301-304), rows of this tile: lane = (row, a quarter of the
@@ -980,7 +1070,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             }
             STAMPW(8);
             if constexpr (C::HAS_U) {          // take over the partner's h1l (same register layout as a stash)
-                flag_wait(flagL + rt * ST, step_no);
+                flag_wait(flagL + rt * ST, step_no, flagE);
                 const int ln = opaque_lane();
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
@@ -993,16 +1083,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                     }
             }
         } else {
-#ifdef FT_DEPHASE
-            __builtin_amdgcn_s_sleep(FT_DEPHASE);          // start half a layer behind the partner wave
-#endif
             STAMPW(0);
             fwd_rows<C, KS_E0>(T3, ST, arena + C::off_of(L_V0), T1, slope, rt, s1);
             STAMPW(1);
             fwd_rows<C, KS_H>(T1, ST, arena + C::off_of(L_V1), T4, slope, rt, s2);
             STAMPW(2);
             fwd_head<C, DL, true>(T4, arena + C::off_of(L_V2), sV, rt);
-            flag_raise(flagV + rt * ST, step_no);
+            if (!(A.fault & 1)) flag_raise(flagV + rt * ST, step_no);      // (fault injection: tests/test_gpu_fused.py)
             STAMPW(3);
             if constexpr (C::HAS_U) {
                 {
@@ -1011,13 +1098,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 }
                 flag_raise(flagL + rt * ST, step_no);
                 STAMPW(4);
-                flag_wait(flagG + rt * ST, step_no);
+                flag_wait(flagG + rt * ST, step_no, flagE);
                 fwd_rows<C, KS_H>(T1, ST, arena + C::off_of(L_L1), T0, slope, rt, s3);
                 STAMPW(5);
                 fwd_head<C, DL, true>(T0, arena + C::off_of(L_L2), sL, rt);
                 STAMPW(6);
             }
-            flag_wait(flagZ + rt * ST, step_no);
+            flag_wait(flagZ + rt * ST, step_no, flagE);
             STAMPW(7);
             // latent log-densities log q(z|x,u), log p(z|u) (nets.py:306-314), rows of this tile
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // own sV / sL rows
@@ -1031,82 +1118,71 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             }
         }
         BAR(8);
-#ifdef FT_ABL_NOBWD            // timing experiment only
-        if (A.n_steps < 0) {
-#endif
 
         // ---- BF3: d2f -> T1; decoder-head gradient -> T0 + STG_F2 (waves 0-3)
         dgrad_hidden<C, SS, DD, KS_H, H>(sO, SS, arena + C::off_of(L_F2), T4, T1, slope, w);
         if (w < 4) wgrad_tile<C, DD, KS_H, H>(sO, SS, T4, ST, T0 + C::STG_F2, 0, w);
         BAR(9);
         // ---- BF2: d1f -> T4; layer-2 gradient -> T0; Adam(F2)
-        stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_F1), T2, T4, slope, w); },
-                LAMBDA { wgrad_pair<C, H, KS_H, H, true>(T1, ST, T2, ST, T0, w);     // guarded: the tile's tail holds the F2 stage
-                         ADAM(L_F2, T0 + C::STG_F2); });
+        dgrad_wgrad_hidden<C, true>(T1, arena + C::off_of(L_F1), T2, T4, T0, slope, w);  // guarded: the tile's tail holds the F2 stage
+        ADAM(L_F2, T0 + C::STG_F2);
         BAR(10);
-        // ---- BF1: dLoss/dz -> sD (waves 0-3); layer-1 gradient -> stF0 (waves 4-7); Adam(F1)
+        // ---- BF1: dLoss/dz (waves 0-3) and, by the lanes that hold it, the head deltas in place (SURVEY §8 a-bwd): sG <- dg,
+        //           sV <- dlogv, sL <- dlogl (rows of the wave's own tile: nothing else reads them in this phase); h2g -> T2;
+        //           layer-1 gradient -> stF0 (waves 4-7); Adam(F1)
         stagger(w, LAMBDA {
             if (w < 4) {
+                // operands of the element-wise part first: they do not depend on the product
+                float zz[4], vv[4], gg[4], ll[4];
+                const int e0 = mul24(16 * rt + 4 * q, SS) + min(c, SS - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    zz[r] = sZ[e0 + r * SS]; vv[r] = sV[e0 + r * SS]; gg[r] = sG[e0 + r * SS];
+                    ll[r] = C::HAS_U ? sL[e0 + r * SS] : 1.f;
+                }
                 const f32x4 acc = mm_dgrad1<KS_H, H, KS_F0>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F0) + min(c, KS_F0 - 1), q);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (c < DL) sD[(16 * rt + 4 * q + r) * SS + c] = acc[r];
+                for (int r = 0; r < 4; ++r) {
+                    const float dq = zz[r] - gg[r];
+                    const float rr = dq * __builtin_amdgcn_rcpf(vv[r]);
+                    const float zl = C::HAS_U ? zz[r] * __builtin_amdgcn_rcpf(ll[r]) : zz[r];
+                    const float Gz = acc[r] - wB * (A.b * rr - A.d * zl);
+                    if (c < DL) {
+                        sG[e0 + r * SS] = wB * A.b * rr + Gz;
+                        sV[e0 + r * SS] = -wB * A.b * 0.5f * (1.f - dq * rr) + Gz * 0.5f * dq;
+                        if constexpr (C::HAS_U) sL[e0 + r * SS] = wB * A.d * 0.5f * (1.f - zz[r] * zl);
+                    }
+                }
+                restore_rows<C>(s2, T2, rt);
             } else {
                 wgrad_tile<C, H, KS_F0, DL>(T4, ST, sZ, SS, stF0, w - 4, 0);
             }
         }, LAMBDA { ADAM(L_F1, T0); });
-        BAR(11);
-        // ---- E: head deltas in place (SURVEY §8 a-bwd): sG <- dg, sV <- dlogv, sL <- dlogl; Adam(F0);
-        //         h2g -> T2, h1g -> T4 (operands of the encoder's weight gradients)
-        for (int e = tid; e < FT_B * SS; e += FT_THREADS) {
-            const int b = e / SS, k = e - b * SS;
-            float dg = 0.f, dv = 0.f, dl = 0.f;
-            if (k < DL) {
-                const float zz = sZ[e], vv = sV[e];
-                const float dq = zz - sG[e];
-                const float rr = dq * __builtin_amdgcn_rcpf(vv);
-                const float zl = C::HAS_U ? zz * __builtin_amdgcn_rcpf(sL[e]) : zz;
-                const float Gz = sD[e] - wB * (A.b * rr - A.d * zl);
-                dg = wB * A.b * rr + Gz;
-                dv = -wB * A.b * 0.5f * (1.f - dq * rr) + Gz * 0.5f * dq;
-                dl = wB * A.d * 0.5f * (1.f - zz * zl);
-            }
-            sG[e] = dg; sV[e] = dv;
-            if constexpr (C::HAS_U) sL[e] = dl;
-        }
-        ADAM(L_F0, stF0);
-        if (w < 4) { restore_rows<C>(s2, T2, rt); restore_rows<C>(s1, T4, rt); }
         {   // loss reduction (deterministic): wave shuffle -> 8 partials -> thread 0 (next phase)
             float v = lsum;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
             if (lane == 0) red[w] = v;
         }
-        BAR(12);
+        BAR(11);
 
-        // ---- G3: d2g -> T0; head gradient -> sZ (z is dead); loss out
+        // ---- G3: d2g -> T0; head gradient -> sZ (z is dead); loss out; Adam(F0); h1g -> T4
         if (tid == 0) {
             const float t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-            A.loss_out[(size_t)model * A.n_steps_total + A.step_begin + s] = -t * wB;
+            A.loss_out[(size_t)model * A.n_steps_total + A.step_begin + s] = *(lds_flag_t*)flagE ? __builtin_nanf("") : -t * wB;
         }
-        STAMPB(0);
-        dgrad_hidden<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), T2, T0, slope, w);
-        STAMPB(1);
-        if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
-        STAMPB(2);
+        stagger(w, LAMBDA {
+                    dgrad_hidden<C, SS, DL, KS_H, H>(sG, SS, arena + C::off_of(L_G2), T2, T0, slope, w);
+                    if (w < 4) wgrad_tile<C, DL, KS_H, H>(sG, SS, T2, ST, sZ, 0, w);
+                }, LAMBDA { ADAM(L_F0, stF0); if (w < 4) restore_rows<C>(s1, T4, rt); });
         BAR(13);
         // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
-        STAMPB(3);
-        stagger(w, LAMBDA { STAMPB(4); dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_G1), T4, T2, slope, w); STAMPB(5); },
-                LAMBDA { STAMPB(6); wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); STAMPB(7); ADAM(L_G2, sZ); STAMPB(8); });
-        STAMPB(9);
+        dgrad_wgrad_hidden<C, false>(T0, arena + C::off_of(L_G1), T4, T2, T1, slope, w);
+        ADAM(L_G2, sZ);
         BAR(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
-        STAMPB(10);
         WGRAD_ADAM(H, KS_E0, C::KIN, T2, ST, T3, ST, T0, L_G1, T1);
-        STAMPB(11);
         if (w >= 4) restore_rows<C>(s2, T4, rt);
-        STAMPB(12);
         BAR(15);
 
         // ---- V3: d2v -> T1; head gradient -> sZ; Adam(G0); h1v -> T2
@@ -1116,8 +1192,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 }, LAMBDA { ADAM(L_G0, T0); if (w >= 4) restore_rows<C>(s1, T2, rt); });
         BAR(16);
         // ---- V2: d1v -> T4; layer-2 gradient -> T0; Adam(V2)
-        stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T1, ST, arena + C::off_of(L_V1), T2, T4, slope, w); },
-                LAMBDA { wgrad_pair<C, H, KS_H, H>(T1, ST, T2, ST, T0, w); ADAM(L_V2, sZ); });
+        dgrad_wgrad_hidden<C, false>(T1, arena + C::off_of(L_V1), T2, T4, T0, slope, w);
+        ADAM(L_V2, sZ);
         BAR(17);
         // ---- V1: layer-1 gradient -> T1; Adam(V1); h2l -> T2
         WGRAD_ADAM(H, KS_E0, C::KIN, T4, ST, T3, ST, T1, L_V1, T0);
@@ -1132,16 +1208,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                     }, LAMBDA { ADAM(L_V0, T1); if (w < 4) restore_rows<C>(s3, T4, rt); });
             BAR(19);
             // ---- L2: d1l -> T2; layer-2 gradient -> T1; Adam(L2)
-            stagger(w, LAMBDA { dgrad_hidden<C, KS_H, H, KS_H, H>(T0, ST, arena + C::off_of(L_L1), T4, T2, slope, w); },
-                    LAMBDA { wgrad_pair<C, H, KS_H, H>(T0, ST, T4, ST, T1, w); ADAM(L_L2, sZ); });
+            dgrad_wgrad_hidden<C, false>(T0, arena + C::off_of(L_L1), T4, T2, T1, slope, w);
+            ADAM(L_L2, sZ);
             BAR(20);
             // ---- L1: layer-1 gradient -> T0; Adam(L1)
             WGRAD_ADAM(H, KS_L0, M, T2, ST, T3 + C::UOFF, ST, T0, L_L1, T1);
             BAR(21);
         }
-#ifdef FT_ABL_NOBWD
-        }
-#endif
     }
     // Adam of the last step's last layer
     if (A.n_steps > 0) {

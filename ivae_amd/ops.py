@@ -310,6 +310,7 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
                 beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False, want_z_steps=False):
     """ivae_train_steps: n_steps fused (elbo -> backward -> Adam) iterations for all packed models.
     params/exp_avg/exp_avg_sq (n_models, P) are updated in place; batch_idx (n_models, n_steps, B) int32.
+    `lr`: one learning rate, or a sequence of n_models of them (packed runs with their own schedulers).
     Returns (loss (n_models, n_steps), z of the last step or None); with want_z_steps the second value is the
     (n_models, n_steps, B, latent) z of every step instead."""
     for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (x_data, "x_data")):
@@ -320,6 +321,12 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
     n_models, n_steps, B = batch_idx.shape
     if params.shape[0] != n_models or x_data.shape[0] != n_models:
         raise ValueError("params / x_data / batch_idx disagree on n_models")
+    model_lr = None
+    if isinstance(lr, (list, tuple)):
+        if len(lr) != n_models:
+            raise ValueError("lr must be one value or one per model")
+        ref = max(float(v) for v in lr)
+        model_lr, lr = (C.c_double * n_models)(*[float(v) for v in lr]), (ref if ref > 0 else 1.0)
     if shape.aux_dim > 0:
         u_data = _f32c(u_data, "u_data")
     else:
@@ -338,7 +345,7 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
               if want_z_steps else None)
         check(_lib.lib().ivae_train_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
                                           _ptr(x_data), _ptr(u_data), x_data.shape[1], _ptr(batch_idx), _ptr(eps),
-                                          int(seed), n_steps, int(step0), float(lr), float(beta1), float(beta2),
+                                          int(seed), n_steps, int(step0), float(lr), model_lr, float(beta1), float(beta2),
                                           float(adam_eps), _ptr(loss), _ptr(z), _ptr(zs), _stream(dev)),
               "ivae_train_steps")
     return loss, (zs if want_z_steps else z)

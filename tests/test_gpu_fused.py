@@ -217,3 +217,55 @@ def test_unsupported_shape_is_refused():
     shape = ops.ModelShape(5, 5, 40, 100, 3, "xtanh", .1)
     assert not ops.train_steps_supported(shape, 64)
     assert not ops.train_steps_supported(ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1), 32)
+
+
+def test_missed_wave_handoff_is_reported_as_nan_loss():
+    """The forward stage's waves hand tiles to each other through LDS flags with a bounded wait.  A wait that runs out (here
+    forced: ivae_debug_fault_inject makes the variance chain skip its flag) must not pass as training: the model's
+    losses are NaN from that step on."""
+    from ivae_amd import _lib
+    spec = np_ref.Spec(10, 10, 40)
+    shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
+    X, U, idx, eps = make_problem(spec, 2, 3, N=100, seed=4)
+    d = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    from ivae_amd.trainer import init_packed_params
+    coef = ops.make_coef(decoder_var=.01, global_batch=64)
+    p = init_packed_params(shape, 2, 0, d)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    try:
+        assert _lib.lib().ivae_debug_fault_inject(1) == 0
+        loss, _ = ops.train_steps(shape, coef, p, m, v, t(X), t(U), t(idx), 0, 1e-2, eps=t(eps))
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().ivae_debug_fault_inject(0)
+    assert torch.isnan(loss).all(), loss
+    p = init_packed_params(shape, 2, 0, d)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    loss, _ = ops.train_steps(shape, coef, p, m, v, t(X), t(U), t(idx), 0, 1e-2, eps=t(eps))
+    assert torch.isfinite(loss).all()
+
+
+def test_per_model_learning_rates():
+    """model_lr: every packed model steps with its own rate -- model 1 at lr/10 equals a separate call at lr/10 bit for bit
+    up to the rate factor's rounding (1e-6), model 0 equals the shared-rate call bit for bit."""
+    spec = np_ref.Spec(10, 10, 40)
+    shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
+    X, U, idx, eps = make_problem(spec, 2, 6, N=200, seed=8)
+    d = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    from ivae_amd.trainer import init_packed_params
+    coef = ops.make_coef(decoder_var=.01, global_batch=64)
+
+    def run(lr, models=slice(0, 2)):
+        p = init_packed_params(shape, 2, 0, d)[models].contiguous()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        loss, _ = ops.train_steps(shape, coef, p, m, v, t(X[models]), t(U[models]), t(idx[models]), 0, lr, eps=t(eps[models]))
+        return loss, p
+
+    l_mix, p_mix = run([1e-2, 1e-3])
+    l_hi, p_hi = run(1e-2)
+    l_lo, p_lo = run(1e-3, slice(1, 2))
+    assert torch.equal(l_mix[0], l_hi[0]) and torch.equal(p_mix[0], p_hi[0])
+    assert torch.allclose(l_mix[1], l_lo[0], rtol=1e-5) and torch.allclose(p_mix[1], p_lo[0], rtol=1e-4, atol=1e-6)
+    assert not torch.allclose(p_mix[1], p_hi[1], atol=1e-4)

@@ -6,17 +6,17 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["IVAE_AMD_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ivae_amd",
-                                          "libivae_amd_prof.so")
+os.environ.setdefault("IVAE_AMD_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ivae_amd",
+                                          "libivae_amd_diag.so"))
 import numpy as np
 import torch
 from ivae_amd import _lib, ops
 from ivae_amd.trainer import FusedPackedTrainer
 
-LABELS = ["P0 adam(last) + XU/eps -> LDS", "FWD wave-local chains (g|v, decoder|prior)", "-", "-", "-",
-          "-", "-", "-", "BF3 dgrad+wgrad head", "BF2 dgrad+wgrad+adam",
-          "BF1 dz | wgrad + adam", "E deltas + adam + restore", "G3", "G2", "G1", "V3", "V2", "V1", "L3", "L2", "L1"]
-NSEG = len(LABELS)
+# (stamp slot written after the barrier that ENDS the phase, label); slot 0 = step start
+PHASES = [(1, "P0 adam(last) + XU/eps -> LDS"), (8, "FWD wave-local chains (g|v, decoder|prior)"), (9, "BF3 dgrad+wgrad head"),
+          (10, "BF2 dgrad->wgrad stream + adam"), (11, "BF1 dz + head deltas | wgrad + adam"), (13, "G3"), (14, "G2"), (15, "G1"),
+          (16, "V3"), (17, "V2"), (18, "V1"), (19, "L3"), (20, "L2"), (21, "L1")]
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = 24
@@ -34,13 +34,15 @@ buf = torch.zeros(steps * NST, dtype=torch.int64, device=dev)
 assert _lib.lib().ivae_debug_set_prof(C.c_void_p(buf.data_ptr())) == 0
 tr.run(steps)
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(steps, NST)[:, :NSEG].astype(np.float64)
-seg = np.diff(np.concatenate([t[:-1], t[1:, :1]], 1), axis=1)[4:]      # (steps-1, 34) cycles per segment
+allst = buf.cpu().numpy().reshape(steps, NST).astype(np.float64)
+ids = [0] + [i for i, _ in PHASES]
+t = allst[:, ids]
+seg = np.diff(np.concatenate([t[:-1], t[1:, :1]], 1), axis=1)[4:]      # cycles per phase (the last one ends at the next step's start)
 mean = seg.mean(0)
 tot = mean.sum()
 print(f"models={M}  cycles/step (wave 0 of model 0): {tot:.0f}")
-for l, c in zip(LABELS, mean):
-    print(f"  {l:28s} {c:9.0f}  {100*c/tot:5.1f}%")
+for (_, l), c in zip(PHASES, mean):
+    print(f"  {l:44s} {c:9.0f}  {100*c/tot:5.1f}%")
 # forward-stage timeline of wave 0 (g chain, decoder; slots 32..) and wave 4 (logv chain, prior; slots 48..), cycles from
 # the stage's first stamp of wave 0
 raw = buf.cpu().numpy().reshape(steps, NST).astype(np.float64)[6:]
@@ -53,10 +55,3 @@ for wv, base, names in (("wave0", 32, names0), ("wave4", 48, names4)):
 print("wave0 g L1: product took", int((raw[:, 32 + 9] - raw[:, 32 + 1]).mean()), "epilogue", int((raw[:, 32 + 2] - raw[:, 32 + 9]).mean()))
 print("stage barrier released (STAMP 8) @", int((raw[:, 8] - raw[:, 32]).mean()))
 
-# backward stamps of G3 / G2 / G1, waves 0 and 4, cycles since the phase's barrier release on wave 0
-for wv, base in (("wave0", 64), ("wave4", 96)):
-    def rel(i, ref):
-        return int((raw[:, base + i] - raw[:, ref]).mean())
-    print(wv, "G3: start", rel(0, 12), "dgrad done", rel(1, 12), "wgrad_tile done", rel(2, 12), "| barrier13 @", int((raw[:, 13] - raw[:, 12]).mean()))
-    print(wv, "G2: start", rel(3, 13), "matrix half", rel(4, 13), "->", rel(5, 13), " vector half wgrad", rel(6, 13), "->", rel(7, 13), "adam ->", rel(8, 13), "end", rel(9, 13), "| barrier14 @", int((raw[:, 14] - raw[:, 13]).mean()))
-    print(wv, "G1: start", rel(10, 14), "wgrad+adam done", rel(11, 14), "restore done", rel(12, 14), "| barrier15 @", int((raw[:, 15] - raw[:, 14]).mean()))
