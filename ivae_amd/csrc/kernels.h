@@ -1,6 +1,7 @@
 // Internal launcher declarations (one per .hip translation unit).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "layout.h"
 
 hipError_t launch_forward(const Layout& L, const IvaeCoef& C, const float* params, const float* x, const float* u,
@@ -46,19 +47,27 @@ hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks,
 hipError_t launch_corr_static(const float* x, const float* y, int64_t n, int d, double* cc, hipStream_t st);
 #define CORR_STATIC_MAX_D 40
 
-// Dynamic LDS above 64 KB needs the function attribute; it is raised only when a launch needs more than what this
-// process has already asked for ON THE CURRENT DEVICE (the attribute is per device; the cache is a plain array of
-// monotonically growing values, so a race between host threads only costs a redundant call).
+// Dynamic LDS above 64 KB needs the function attribute.  hipFuncSetAttribute SETS the limit (it does not take a maximum),
+// and host threads may launch the same kernel with different sizes at the same moment (sweep.py trains one pack per
+// thread and stream): check, call and cache update therefore happen under one lock, so the attribute ON THE CURRENT
+// DEVICE only ever grows and the cached value never exceeds it.  The lock-free early return is safe for the same
+// reason: a cached value was written after the attribute had been raised to it.
 #define IVAE_MAX_DEVICES 64
 struct SmemCache { int v[IVAE_MAX_DEVICES]; };
+inline std::mutex& smem_mutex() {
+    static std::mutex m;
+    return m;
+}
 static inline hipError_t set_smem(const void* fn, int bytes, SmemCache& cache) {
     if (bytes <= 64 * 1024) return hipSuccess;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const bool cached = dev >= 0 && dev < IVAE_MAX_DEVICES;
+    if (cached && bytes <= __atomic_load_n(&cache.v[dev], __ATOMIC_ACQUIRE)) return hipSuccess;
+    std::lock_guard<std::mutex> lock(smem_mutex());
     if (cached && bytes <= cache.v[dev]) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess && cached) cache.v[dev] = bytes;
-    return e;
+    if (e == hipSuccess && cached) __atomic_store_n(&cache.v[dev], bytes, __ATOMIC_RELEASE);
+    return e;      // (a device index past the cache: the attribute is set on every launch, still under the lock)
 }

@@ -25,7 +25,7 @@ from scipy.optimize import linear_sum_assignment
 from . import ops
 from .data import generate_data
 from .dist import gather_model_results, model_range
-from .trainer import FusedPackedTrainer, PackedTrainer
+from .trainer import FusedPackedTrainer, PackedTrainer, PlateauLR
 
 
 def device_datasets(n_models, n_seg, n_per_seg, d, seeds, device):
@@ -86,20 +86,38 @@ def evaluate_pack(shape, params, x, u, s_true, rows_per_call=8192, seed=0):
     return np.array([c[linear_sum_assignment(-c)].mean() for c in cc])
 
 
+def train_pack(tr, n_models, epochs, steps_per_epoch, lr, patience):
+    """`epochs` passes over a pack's datasets.  After every epoch each run's own ReduceLROnPlateau(factor .1, patience)
+    sees that run's mean epoch loss (runners/ivae.py:39,108-114; wrappers.py:45,82-83) and the pack's next epoch is
+    launched with one learning rate per run (`model_lr` of ivae_train_steps / ivae_elbo_adam_steps); patience None = no
+    scheduler (`no_scheduler: True`).  One host sync per epoch (the reference syncs every step).  -> final rates."""
+    sched = None if patience is None else PlateauLR(n_models, lr, factor=0.1, patience=patience)
+    lrs = [float(lr)] * n_models
+    for _ in range(epochs):
+        tr.lr = lrs if sched is not None else lr
+        out = tr.run(steps_per_epoch)
+        if sched is not None:
+            losses = out if isinstance(tr, FusedPackedTrainer) else tr.last_losses         # (n_models, steps)
+            lrs = sched.step(losses.double().mean(1).cpu().tolist())
+    return lrs
+
+
 def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2, hidden=50, data="host",
-              device=None, rank=0, world=1, log=None, concurrent=True):
+              device=None, rank=0, world=1, log=None, concurrent=True, patience=0, lr_out=None):
     """Runs this rank's share of the (dim, seed) grid; returns (local run ids, local MCCs, seconds spent training,
     training steps x models done).  concurrent: the packs of the different latent dimensions train at the same time, each
     on a HIP stream of its own -- a 64-model pack of the fused kernel occupies 64 of the 256 CUs and a 64-model pack of
     the generic kernels is latency-bound, so one pack at a time leaves most of the chip idle; the packs are independent,
-    their results do not depend on the interleaving."""
+    their results do not depend on the interleaving.  patience: of every run's ReduceLROnPlateau (0 as in
+    runners/ivae.py:39; None: constant learning rate); lr_out: a dict that receives {run index: final learning rate}."""
     device = device or torch.device("cuda", 0)
     runs = [(d, s) for d in dims for s in range(n_seeds)]
     lo, hi = model_range(len(runs), rank, world)
     mine = runs[lo:hi]
     mcc_local = np.zeros(hi - lo)
     N = n_seg * n_per_seg
-    steps = epochs * (N // batch)
+    nb = N // batch
+    steps = epochs * nb
     packs = []
     for d in sorted({r[0] for r in mine}):
         idx = [i for i, r in enumerate(mine) if r[0] == d]
@@ -124,7 +142,8 @@ def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2
         def train(p, st):      # a host thread per pack: a launch call blocks while its stream's queue is full, and the
             torch.cuda.set_device(device)       # library calls (a whole epoch each) run without the interpreter lock
             with torch.cuda.stream(st):
-                p["tr"].run(steps)       # fused: ivae_train_steps launches; generic: one ivae_elbo_adam_steps call per epoch
+                # fused: ivae_train_steps launches; generic: one ivae_elbo_adam_steps call per epoch
+                p["lrs"] = train_pack(p["tr"], p["n"], epochs, nb, lr, patience)
         with ThreadPoolExecutor(len(order)) as pool:
             for f in [pool.submit(train, p, st) for p, st in zip(order, streams)]:
                 f.result()
@@ -134,13 +153,15 @@ def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2
         for p in packs:
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            p["tr"].run(steps)
+            p["lrs"] = train_pack(p["tr"], p["n"], epochs, nb, lr, patience)
             torch.cuda.synchronize(device)
             t_train += time.perf_counter() - t0
     for p in packs:
         work += steps * p["n"]
         m = evaluate_pack(p["shape"], p["tr"].params, p["x"], p["u"], p["s"], seed=p["d"])
         mcc_local[p["idx"]] = m
+        if lr_out is not None:
+            lr_out.update({lo + i: v for i, v in zip(p["idx"], p["lrs"])})
         if log:
             log("rank %d: d=%d, %d runs, %s, %d steps: MCC mean %.3f (min %.3f, max %.3f)" % (
                 rank, p["d"], p["n"], "fused" if p["fused"] else "generic", steps, m.mean(), m.min(), m.max()))
@@ -160,6 +181,8 @@ def main():
                     help="host (default): the bit-exact numpy generator of data/data.py, as north_star asks (seconds per "
                          "dataset); device: a throughput-only stand-in drawn on the GPU WITHOUT the generator's "
                          "condition-number rejection -- its MCCs are not on reference inputs")
+    ap.add_argument("--no-scheduler", action="store_true", help="constant learning rate (the reference's no_scheduler: True); "
+                                                                "default: every run has its own ReduceLROnPlateau(factor .1, patience 0)")
     ap.add_argument("--serial", action="store_true", help="train one pack (latent dimension) at a time instead of all "
                                                           "of them concurrently on separate streams")
     args = ap.parse_args()
@@ -174,7 +197,8 @@ def main():
     t0 = time.perf_counter()
     (lo, hi), mcc, t_train, work = run_sweep(dims, args.seeds, args.epochs, args.ns, args.nps, args.batch, args.lr,
                                              data=args.data, device=dev, rank=rank, world=world,
-                                             log=lambda s: print(s, flush=True), concurrent=not args.serial)
+                                             log=lambda s: print(s, flush=True), concurrent=not args.serial,
+                                             patience=None if args.no_scheduler else 0)
     n_runs = len(dims) * args.seeds
     allm = gather_model_results(torch.from_numpy(mcc).to(dev), n_runs).cpu().numpy()
     stats = torch.tensor([t_train, float(work)], device=dev, dtype=torch.float64)
@@ -191,6 +215,7 @@ def main():
             per_dim[str(d)] = {"mcc_mean": round(float(m.mean()), 4), "mcc_std": round(float(m.std()), 4)}
         print(json.dumps({"sweep": "iVAE seeds x dims, packed runs", "n_runs": n_runs, "n_gpus": world,
                           "epochs": args.epochs, "batch": args.batch,
+                          "lr_schedule": "constant" if args.no_scheduler else "ReduceLROnPlateau(.1, patience 0) per run",
                           "packs": "one at a time" if args.serial else "concurrent, one HIP stream per latent dimension",
                           "data": ("host numpy generator (bit-exact data/data.py)" if args.data == "host" else
                                    "device stand-in, NOT the reference generator (no condition-number rejection)"),

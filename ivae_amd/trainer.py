@@ -33,6 +33,33 @@ def init_packed_params(shape, n_models, seed, device, xavier=True):
     return torch.cat(parts, 1).contiguous()
 
 
+class PlateauLR:
+    """`ReduceLROnPlateau(optimizer, factor, patience)` (mode 'min', relative threshold 1e-4, no cooldown, min_lr 0, eps
+    1e-8 -- the defaults the reference's loops run with, runners/ivae.py:39, wrappers.py:45) for every run of a pack at
+    once: `step(losses)` takes the runs' mean epoch losses and returns their learning rates.  Same decisions as torch's
+    scheduler run per model (tests/test_api_cpu.py)."""
+
+    def __init__(self, n_models, lr, factor=0.1, patience=0, threshold=1e-4, eps=1e-8):
+        self.lr = [float(lr)] * n_models
+        self.factor, self.patience, self.threshold, self.eps = factor, patience, threshold, eps
+        self.best = [math.inf] * n_models
+        self.bad = [0] * n_models
+
+    def step(self, losses):
+        for i, cur in enumerate(float(v) for v in losses):
+            if cur < self.best[i] * (1.0 - self.threshold):          # torch: is_better, mode 'min', threshold_mode 'rel'
+                self.best[i] = cur
+                self.bad[i] = 0
+            else:
+                self.bad[i] += 1
+            if self.bad[i] > self.patience:
+                new = self.lr[i] * self.factor
+                if self.lr[i] - new > self.eps:
+                    self.lr[i] = new
+                self.bad[i] = 0
+        return list(self.lr)
+
+
 class PackedTrainer:
     """Generic-kernel implementation (any shape): one ivae_forward / ivae_backward / ivae_adam_step
     launch sequence per step covers all models."""
@@ -98,8 +125,8 @@ class PackedTrainer:
 
     def run(self, n_steps):
         """n_steps steps with one `ivae_elbo_adam_steps` call per stretch of an epoch (same kernels and update as
-        `step`; the noise of a stretch is one draw)."""
-        done = 0
+        `step`; the noise of a stretch is one draw).  `self.lr`: one learning rate or a list of one per model."""
+        done, out = 0, []
         while done < n_steps:
             if self._batches is None or self._cursor >= self._batches:
                 self._reshuffle()
@@ -114,6 +141,8 @@ class PackedTrainer:
             self.t += k
             done += k
             self._loss, self._z = loss[-1], z[-1]
+            out.append(loss.t())
+        self.last_losses = torch.cat(out, 1) if len(out) > 1 else out[0]          # (n_models, n_steps)
         return self._loss
 
     def losses(self):

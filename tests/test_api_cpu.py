@@ -198,3 +198,24 @@ def test_pairwise_workspace_size_is_reported_without_a_gpu():
     assert L.ivae_pairwise_workspace_bytes(0, 64, 5, C.byref(n)) == -1
     assert L.ivae_pairwise_workspace_bytes(64, 64, 65, C.byref(n)) == -4
     assert L.ivae_pairwise_workspace_bytes(64, 64, 5, None) == -3
+
+
+def test_pack_plateau_scheduler_equals_torch_per_model():
+    """ivae_amd.trainer.PlateauLR (one instance for a whole pack) takes the decisions torch's ReduceLROnPlateau takes when
+    run once per model (runners/ivae.py:39: factor .1, patience 0; wrappers.py:45: patience 3)."""
+    import numpy as np
+    import torch
+    from ivae_amd.trainer import PlateauLR
+    rng = np.random.RandomState(0)
+    for patience in (0, 3):
+        losses = -500 - np.cumsum(rng.randn(40, 5) * 2 + 0.5, 0)          # noisy descents, negative like the ELBO losses
+        losses[25:] += np.linspace(0, 30, 15)[:, None]                   # ... that turn upwards
+        ours = PlateauLR(5, 1e-2, factor=0.1, patience=patience)
+        ref_opt = [torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=1e-2) for _ in range(5)]
+        ref = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, factor=0.1, patience=patience) for o in ref_opt]
+        for e in range(40):
+            got = ours.step(losses[e])
+            for m in range(5):
+                ref[m].step(float(losses[e, m]))
+                assert got[m] == ref_opt[m].param_groups[0]["lr"], (patience, e, m)
+        assert len(set(got)) > 1 or got[0] < 1e-2

@@ -33,6 +33,94 @@ def test_concurrent_packs_equal_serial_packs():
     assert np.array_equal(mcc_c, mcc_s)
 
 
+def test_two_threads_whose_packs_need_different_lds_sizes():
+    """Two host threads launch the SAME kernels with different dynamic-LDS needs above 64 KB at the same moment (256-model
+    packs at d = 12 and d = 20): the attribute update is serialised in the library (kernels.h::set_smem), so every launch
+    succeeds and each pack's result equals what it gives alone."""
+    import threading
+    from ivae_amd import ops
+    from ivae_amd.trainer import PackedTrainer
+    dev = torch.device("cuda:0")
+
+    def make(d):
+        shape = ops.ModelShape(d, d, 40, 50, 3, "lrelu", .1)
+        tr = PackedTrainer(shape, n_models=256, batch=64, lr=1e-2, seed=d, device=dev)
+        g = torch.Generator(device=dev).manual_seed(d)
+        x = torch.randn(256, 128, d, generator=g, device=dev)
+        u = torch.zeros(256, 128, 40, device=dev)
+        u[:, torch.arange(128), torch.arange(128) % 40] = 1
+        tr.set_data(x, u)
+        return tr
+
+    alone = {}
+    for d in (12, 20):
+        tr = make(d)
+        tr.run(2)
+        alone[d] = tr.params.clone()
+    for attempt in range(3):
+        trs = {d: make(d) for d in (12, 20)}
+        errs, gate = [], threading.Barrier(2)
+
+        def work(d):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(torch.cuda.Stream(dev)):
+                    gate.wait()
+                    trs[d].run(2)
+            except Exception as e:          # noqa: BLE001 -- reported below
+                errs.append((d, repr(e)))
+
+        th = [threading.Thread(target=work, args=(d,)) for d in (12, 20)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize(dev)
+        assert not errs, errs
+        for d in (12, 20):
+            assert torch.equal(trs[d].params, alone[d]), d
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_every_run_of_a_pack_has_its_own_plateau_scheduler(fused):
+    """sweep.train_pack: after each epoch every run's ReduceLROnPlateau(factor .1, patience 0) sees its own mean epoch loss
+    (runners/ivae.py:39,108-114) and the next epoch runs with one learning rate per run.  Checked against the same epochs
+    driven by hand with one torch scheduler per run: same rates at every epoch, same parameters bit for bit; the runs do
+    not all cut at the same epoch."""
+    from ivae_amd import ops
+    from ivae_amd.sweep import train_pack
+    from ivae_amd.trainer import FusedPackedTrainer, PackedTrainer
+    dev = torch.device("cuda:0")
+    d = 10 if fused else 12
+    shape = ops.ModelShape(d, d, 40, 50, 3, "lrelu", .1)
+    M, N, epochs = 6, 640, 120         # 1200 steps: long enough for every run's epoch mean to stop improving somewhere
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(M, N, d, generator=g, device=dev) * torch.linspace(.5, 3, M, device=dev)[:, None, None]
+    u = torch.zeros(M, N, 40, device=dev)
+    u[:, torch.arange(N), torch.arange(N) % 40] = 1
+
+    def make():
+        tr = (FusedPackedTrainer if fused else PackedTrainer)(shape, n_models=M, batch=64, lr=1e-2, seed=5, device=dev)
+        tr.set_data(x, u)
+        return tr
+
+    tr = make()
+    lrs = train_pack(tr, M, epochs, N // 64, 1e-2, 0)
+    ref = make()
+    opts = [torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=1e-2) for _ in range(M)]
+    scheds = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, factor=0.1, patience=0) for o in opts]
+    history = []
+    for _ in range(epochs):
+        ref.lr = [o.param_groups[0]["lr"] for o in opts]
+        out = ref.run(N // 64)
+        losses = (out if fused else ref.last_losses).double().mean(1).cpu().tolist()
+        for sc, l in zip(scheds, losses):
+            sc.step(l)
+        history.append([o.param_groups[0]["lr"] for o in opts])
+    assert lrs == history[-1]
+    assert torch.equal(tr.params, ref.params)
+    first_cut = [next((e for e, h in enumerate(history) if h[m] < 1e-2), None) for m in range(M)]
+    assert any(c is not None for c in first_cut) and len(set(first_cut)) > 1, first_cut
+
+
 def test_two_rank_split_covers_the_grid_once():
     """Rank shares of the run list are disjoint and complete (no GPU work: the partition rule only)."""
     from ivae_amd.dist import model_range
