@@ -146,10 +146,14 @@ int ivae_backward(const IvaeDims* dims, const IvaeCoef* coef, const float* param
  *   eps_steps (n_steps, n_models, batch, latent_dim)
  * and writes loss_out (n_steps, n_models) and z_steps (n_steps, n_models, batch, latent_dim).
  * params / exp_avg / exp_avg_sq (n_models, P) in/out; grads (n_models, P): scratch for the flat gradient;
- * step0 = Adam steps already taken; lr and the loss weights are constant over the call.
+ * step0 = Adam steps already taken; lr is constant over the call.
+ * coef_steps: NULL (the loss weights `coef` hold for every step), or n_steps loss definitions in HOST memory, read before
+ * the call returns: step s runs with coef_steps[s] (`iVAE.anneal` changes a, b, c, d every iteration and drops the
+ * pairwise terms after max_iter / 1.6 iterations: models/nets.py:477-486, called per step at models/wrappers.py:62-63).
+ * When any of them has pairwise != 0 the workspace must be sized with pairwise = 1.
  * model_lr: NULL, or n_models learning rates in HOST memory that replace `lr` model by model (packed seeds of one
  * `main.py --n-sims K` run: each has its own ReduceLROnPlateau, runners/ivae.py:39,113-114); read before the call returns. */
-int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef,
+int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, const IvaeCoef* coef_steps,
                          float* params, float* exp_avg, float* exp_avg_sq,
                          const float* x_steps, const float* u_steps, const float* eps_steps,
                          int32_t n_steps, int64_t step0,

@@ -61,7 +61,7 @@ def lib():
     L.ivae_pairwise.argtypes = [C.c_int32, C.c_int32, C.c_int32, pc, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_backward.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_adam_step.argtypes = [vp, vp, vp, vp, C.c_int64, f64, f64, f64, f64, C.c_int64, vp]
-    L.ivae_elbo_adam_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int64, f64, C.POINTER(C.c_double), f64, f64,
+    L.ivae_elbo_adam_steps.argtypes = [pd, pc, pc, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int64, f64, C.POINTER(C.c_double), f64, f64,
                                        f64, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_train_steps_supported.argtypes = [pd]
     L.ivae_train_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_uint64, C.c_int32, C.c_int64,

@@ -151,13 +151,15 @@ int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_adam_step");
 }
 
-int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
+int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, const IvaeCoef* coef_steps, float* params,
+                         float* exp_avg, float* exp_avg_sq,
                          const float* x_steps, const float* u_steps, const float* eps_steps, int32_t n_steps,
                          int64_t step0, double lr, const double* model_lr, double beta1, double beta2, double adam_eps, float* loss_out,
                          float* z_steps, float* grads, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = ivae_check_dims(dims);
     if (rc) return rc;
     if (n_steps <= 0 || step0 < 0) return IVAE_E_BADDIMS;
+    if (!coef && !coef_steps) return IVAE_E_NULLPTR;
     if (!params || !exp_avg || !exp_avg_sq || !x_steps || !eps_steps || !loss_out || !z_steps || !grads ||
         (dims->aux_dim > 0 && !u_steps))
         return IVAE_E_NULLPTR;
@@ -175,7 +177,7 @@ int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, float* para
             for (int i = 0; i < dims->n_models; ++i) F.neg_step[i] = (float)(-(model_lr ? model_lr[i] : lr) / bc1);
         }
         bool fused = false;
-        rc = fwd_bwd_impl(dims, coef, params, x_steps + s * rows * dims->data_dim,
+        rc = fwd_bwd_impl(dims, coef_steps ? coef_steps + s : coef, params, x_steps + s * rows * dims->data_dim,
                           u_steps ? u_steps + s * rows * dims->aux_dim : nullptr, eps_steps + s * rows * dims->latent_dim,
                           z_steps + s * rows * dims->latent_dim, loss_out + (size_t)s * dims->n_models, grads, workspace,
                           workspace_bytes, stream, can_fuse ? &F : nullptr, &fused);

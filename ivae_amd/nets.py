@@ -208,13 +208,17 @@ class _FusedModel(nn.Module):
         optimizer.step_flat(flat, grads)
         return loss[0], z
 
-    def direct_steps(self, optimizer, xs, us, a, b, c, d, N, pairwise, eps=None, z_out=None):
+    def direct_steps(self, optimizer, xs, us, a, b, c, d, N, pairwise, eps=None, z_out=None, coefs=None):
         """`direct_step` over the batches xs (n, B, data_dim) [us (n, B, aux_dim)] with ONE library call
-        (`ivae_elbo_adam_steps`): same kernels, same update, constant loss weights and learning rate over the call; the
-        noise of all n steps is one torch.randn draw.  Returns (losses (n,), z (n, B, latent_dim))."""
+        (`ivae_elbo_adam_steps`): same kernels, same update, constant learning rate over the call; the noise of all n steps
+        is one torch.randn draw.  Loss weights: (a, b, c, d, N, pairwise) for every step, or `coefs` = one such tuple per
+        step (the per-iteration schedule of `iVAE.anneal`).  Returns (losses (n,), z (n, B, latent_dim))."""
         if eps is None:
             eps = torch.randn(xs.shape[0], xs.shape[1], self._shape.latent_dim, dtype=torch.float32, device=xs.device)
-        coef = ops.make_coef(a, b, c, d, N, self._decoder_var_f, pairwise, xs.shape[1])
+        if coefs is None:
+            coef = ops.make_coef(a, b, c, d, N, self._decoder_var_f, pairwise, xs.shape[1])
+        else:
+            coef = [ops.make_coef(a_, b_, c_, d_, N_, self._decoder_var_f, pw_, xs.shape[1]) for a_, b_, c_, d_, N_, pw_ in coefs]
         flat = self._flat_params()
         m, v, taken, group = optimizer.flat_state(flat)
         b1, b2 = group['betas']

@@ -158,7 +158,15 @@ def elbo_adam_steps(shape, coef, params, exp_avg, exp_avg_sq, x_steps, u_steps, 
                     beta2=0.999, adam_eps=1e-8, n_models=1, z_out=None):
     """ivae_elbo_adam_steps: x_steps (n_steps, [n_models,] batch, data_dim) etc.; params and the Adam moments are
     updated in place.  `lr`: one learning rate, or a sequence of n_models of them (packed runs with their own
-    schedulers).  -> (loss (n_steps, n_models), z (like eps_steps))."""
+    schedulers).  `coef`: one IvaeCoef, or a sequence of n_steps of them (annealed loss weights: one per step).
+    -> (loss (n_steps, n_models), z (like eps_steps))."""
+    coef_steps = None
+    if isinstance(coef, (list, tuple)):
+        if len(coef) != x_steps.shape[0]:
+            raise ValueError("coef must be one IvaeCoef or one per step")
+        coef_steps = (IvaeCoef * len(coef))(*coef)
+        # the workspace serves every step: sized for the pairwise terms if any step has them
+        coef = next((c for c in coef if c.pairwise), coef[0])
     if isinstance(lr, (list, tuple)):
         if len(lr) != n_models:
             raise ValueError("lr must be one value or one per model")
@@ -188,7 +196,7 @@ def elbo_adam_steps(shape, coef, params, exp_avg, exp_avg_sq, x_steps, u_steps, 
                 raise ValueError("z_out must be a contiguous float32 tensor of eps_steps' size on the inputs' device")
         loss = torch.empty(n_steps, n_models, dtype=torch.float32, device=dev)
         grads = torch.empty_like(params)
-        check(_lib.lib().ivae_elbo_adam_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
+        check(_lib.lib().ivae_elbo_adam_steps(C.byref(dims), C.byref(coef), coef_steps, _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
                                               _ptr(x_steps), _ptr(u_steps), _ptr(eps_steps), int(n_steps), int(step0),
                                               float(lr), model_lr, float(beta1), float(beta2), float(adam_eps), _ptr(loss), _ptr(z),
                                               _ptr(grads), _ptr(buf), buf.numel() * 4, _stream(dev)), "ivae_elbo_adam_steps")

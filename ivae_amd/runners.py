@@ -112,7 +112,7 @@ class _SeedPack:
         return loss, z
 
 
-def runner(args, config, *, replay=None, trace=None):
+def runner(args, config, *, replay=None, trace=None, init_seeds=False):
     """runners/ivae.py:13-128.  `args`: data_path, seed, n_sims.  `config`: the yaml keys of configs/*.yaml plus
     `device`.  Returns (perfs, loss_hists, perf_hists).
 
@@ -124,7 +124,9 @@ def runner(args, config, *, replay=None, trace=None):
     `replay` supplies the random draws instead of the device generators -- `replay.order(seed, epoch)` the epoch's row
     order (N // B * B indices), `replay.eps(seed, epoch)` the (N // B, B, d_latent) noise of its steps,
     `replay.eval_eps(seed)` the (N, d_latent) noise of the final full-data sample; `trace` (a dict) receives the
-    per-step losses, and per epoch the loss weights and the learning rates after the schedulers' steps."""
+    per-step losses, and per epoch the loss weights and the learning rates after the schedulers' steps; `init_seeds`:
+    the model of seed s is drawn after torch.manual_seed(s), i.e. as `main.py --seed s --n-sims 1` draws it, so that
+    recorded single-seed runs of the reference can be replayed as one pack."""
     st = time.time()
     device = torch.device(config.device)
     print('Executing script on: {}\n'.format(device))
@@ -143,7 +145,9 @@ def runner(args, config, *, replay=None, trace=None):
     seeds = list(range(args.seed, args.seed + args.n_sims))
     K = len(seeds)
     models = []
-    for _ in seeds:
+    for sd in seeds:
+        if init_seeds:
+            torch.manual_seed(sd)
         if config.ica:
             models.append(cleanIVAE(data_dim=d_data, latent_dim=d_latent, aux_dim=d_aux, hidden_dim=config.hidden_dim,
                                     n_layers=config.n_layers, activation=config.activation, slope=.1).to(device))
@@ -334,35 +338,41 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                 maybe_checkpoint(it)
         else:
             Ze = torch.empty(n_full, batch_size, d, device=device) if cc is not None else None
-            first = 0
-            if not anneal and n_full:
-                # constant loss weights: the epoch's full batches go through ivae_elbo_adam_steps, one call per piece
+            if n_full:
+                # the epoch's full batches go through ivae_elbo_adam_steps, one call per piece; with anneal on, the loss
+                # weights of every iteration of the piece (model.anneal is called before each step, wrappers.py:62-63)
+                # travel with the call as one coefficient set per step
                 idx = torch.stack(batches[:n_full])
                 for a0, b0 in segments(it, n_full):
+                    coefs = None
+                    if anneal:
+                        coefs = []
+                        for k in range(a0, b0):
+                            model.anneal(N, max_iter, it + 1 + k - a0)
+                            if with_u and model.anneal_params:
+                                coefs.append(tuple(model._training_hyperparams) + (True,))
+                            else:
+                                coefs.append((1., 1., 1., 1., 1., False))
                     losses, _ = model.direct_steps(optimizer, X[idx[a0:b0]], U[idx[a0:b0]] if with_u else None, 1., 1., 1.,
-                                                   1., 1., False, z_out=None if Ze is None else Ze[a0:b0])
+                                                   1., 1., False, z_out=None if Ze is None else Ze[a0:b0], coefs=coefs)
                     logger.update('elbo', losses.sum(), weight=b0 - a0)
                     it += b0 - a0
                     maybe_checkpoint(it)
-                first = n_full
-            for i, bidx in enumerate(batches):
-                if i < first:
-                    continue
+            for i in range(n_full, len(batches)):        # the ragged final batch (wrappers.py:28 has no drop_last)
+                bidx = batches[i]
                 it += 1
-                full = Ze is not None and i < n_full
                 if anneal:
                     model.anneal(N, max_iter, it)
                 # zero_grad -> elbo -> mul(-1).backward() -> step (wrappers.py:64-70) as one launch sequence; the loss
                 # coefficients are what model.elbo would pass (nets.py:457-475)
-                zo = Ze[i] if full else None
                 if with_u and model.anneal_params:
                     a_, b_, c_, d_, N_ = model._training_hyperparams
-                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx], a_, b_, c_, d_, N_, True, z_out=zo)
+                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx], a_, b_, c_, d_, N_, True)
                 else:
                     loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx] if with_u else None, 1., 1., 1., 1., 1.,
-                                                    False, z_out=zo)
+                                                    False)
                 logger.update('elbo', loss)
-                if cc is not None and not full:
+                if cc is not None:
                     cc[i] = corr_matrix_gpu(z_est, Z[bidx])
                 maybe_checkpoint(it)
             if Ze is not None and n_full:

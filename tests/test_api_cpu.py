@@ -52,7 +52,7 @@ def test_bad_shapes_return_error_codes():
     # the many-steps entry point validates before it launches anything: null buffers, step counts, dims
     good = _lib.IvaeDims(64, 10, 10, 40, 50, 3, 1, .1, 1)
     coef = ops.make_coef(global_batch=64)
-    args = lambda dims, n, t0: (C.byref(dims), C.byref(coef), None, None, None, None, None, None, n, t0, .01, None, .9, .999,
+    args = lambda dims, n, t0: (C.byref(dims), C.byref(coef), None, None, None, None, None, None, None, n, t0, .01, None, .9, .999,
                                 1e-8, None, None, None, None, 0, None)
     assert L.ivae_elbo_adam_steps(*args(good, 3, 0)) == -3
     assert L.ivae_elbo_adam_steps(*args(good, 0, 0)) == -1

@@ -197,3 +197,57 @@ def test_direct_steps_equals_direct_step_sequence(family):
     for k in s1:
         assert float(s1[k]['step']) == float(s2[k]['step']) == float(n)
         assert torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) and torch.equal(s1[k]['exp_avg_sq'], s2[k]['exp_avg_sq'])
+
+
+def test_annealed_epoch_in_one_call_equals_the_per_step_sequence():
+    """`iVAE(anneal=True)`: model.anneal(N, max_iter, it) changes the loss weights before every step and switches to the
+    plain ELBO after max_iter / 1.6 iterations (models/nets.py:477-486, wrappers.py:62-63).  An epoch handed to
+    ivae_elbo_adam_steps as ONE call with one coefficient set per step (`coef_steps`) is bit-identical to the loop of
+    direct_step calls it replaces -- across the switch (thr = 6 here) as well."""
+    import copy
+    import torch
+    from ivae_amd import FusedAdam, iVAE
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    m1 = iVAE(6, 6, 12, n_layers=3, hidden_dim=20, activation='lrelu', slope=.1, device=dev, anneal=True).to(dev)
+    m2 = copy.deepcopy(m1)
+    o1, o2 = FusedAdam(m1.parameters(), lr=1e-2), FusedAdam(m2.parameters(), lr=1e-2)
+    g = torch.Generator(device=dev).manual_seed(1)
+    n, B, N, max_iter = 10, 48, 4800, 10
+    xs = torch.randn(n, B, 6, generator=g, device=dev)
+    us = torch.zeros(n, B, 12, device=dev)
+    us.view(-1, 12)[torch.arange(n * B), torch.randint(0, 12, (n * B,), generator=g, device=dev)] = 1
+    eps = torch.randn(n, B, 6, generator=g, device=dev)
+    ref, coefs = [], []
+    for i in range(n):
+        m1.anneal(N, max_iter, i + 1)
+        if m1.anneal_params:
+            w = tuple(m1._training_hyperparams) + (True,)
+        else:
+            w = (1., 1., 1., 1., 1., False)
+        coefs.append(w)
+        ref.append(m1.direct_step(o1, xs[i], us[i], *w, eps=eps[i]))
+    assert [c[5] for c in coefs] == [True] * 6 + [False] * 4            # thr = int(10 / 1.6) = 6: it > thr drops the TC form
+    assert len({c[:4] for c in coefs[:6]}) == 6                          # the weights do change every iteration
+    losses, zs = m2.direct_steps(o2, xs, us, 1., 1., 1., 1., 1., False, eps=eps, coefs=coefs)
+    for i in range(n):
+        assert torch.equal(losses[i], ref[i][0]) and torch.equal(zs[i], ref[i][1]), i
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        assert torch.equal(p1, p2)
+
+
+def test_ivae_wrapper_with_anneal_runs_an_epoch_per_call(tmp_path):
+    """IVAE_wrapper(anneal=True) (wrappers.py:62-63): every epoch's full batches are one ivae_elbo_adam_steps call with a
+    coefficient set per iteration; the ragged batch and the checkpoints keep their iteration numbers, and the schedule
+    reaches the plain ELBO after max_iter / 1.6 iterations."""
+    X, U, S = _cfg2_like(65)                      # 40 full batches + 40 rows per epoch
+    z, model, params, logger = runners.IVAE_wrapper(X, U, S, batch_size=64, max_iter=123, seed=2, hidden_dim=48, lr=1e-2,
+                                                   anneal=True, log_folder=str(tmp_path / 'log'),
+                                                   ckpt_folder=str(tmp_path / 'ckpt') + '/')
+    assert z.shape == (2600, 10) and len(logger.log_dict['elbo']) == 3 and all(np.isfinite(logger.log_dict['elbo']))
+    assert model.anneal_params is False           # it = 123 > thr = int(123 / 1.6) = 76
+    its = sorted(int(os.path.basename(f).split('_ckpt_')[1][:-4]) for f in glob.glob(str(tmp_path / 'ckpt') + '/*/*_ckpt_*.pth'))
+    assert its == [24, 48, 72, 96, 120]
+    for f in glob.glob(str(tmp_path / 'ckpt') + '/*/*_ckpt_*.pth'):
+        ck = torch.load(f, weights_only=True)
+        assert int(ck['optimizer_state_dict']['state'][0]['step']) == ck['iteration']

@@ -246,6 +246,59 @@ def make_traces(n_seeds=4, epochs=2, B=64):
     np.savez_compressed(os.path.join(OUT, "trace_cfg2.npz"), **out)
 
 
+def make_traces_long(n_seeds=4, epochs=10, B=64, n_twins=2):
+    """make_traces at 10 epochs (6250 steps): the reference iVAE of BASELINE configs[1] per seed, plus n_twins runs with
+    the initial parameters moved by 1e-6 relative -> tests/golden/trace_cfg2_long.npz (per-epoch mean losses, first and
+    last step losses, final MCC of a sampled z and of the mean g).  Batch order and noise are reproducible from the seeds
+    (trace_batches, the per-step manual_seed)."""
+    torch.set_num_threads(1)
+    if not hasattr(np, "int"):
+        np.int = int
+    from data.data import generate_data
+    S, X, U, _, _ = generate_data(1000, 40, 10, 10, n_layers=3, seed=1, prior='gauss', activation='lrelu',
+                                  batch_size=0, repeat_linearity=True)
+    Xt, Ut = torch.from_numpy(X), torch.from_numpy(U)
+    N = X.shape[0]
+    nb = N // B
+
+    def run(seed, perturb):
+        torch.manual_seed(seed)
+        model = iVAE(10, 10, 40, n_layers=3, hidden_dim=50, activation='lrelu', slope=.1)
+        if perturb:
+            gen = torch.Generator().manual_seed(4242 + perturb)
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.mul_(1 + 1e-6 * torch.randn(p.shape, generator=gen))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        losses, step = [], 0
+        for epoch in range(epochs):
+            for idx in trace_batches(seed, epoch, N, B):
+                torch.manual_seed(1_000_000 * (seed + 1) + step)
+                opt.zero_grad()
+                elbo, z = model.elbo(Xt[idx], Ut[idx])
+                elbo.mul(-1).backward()
+                opt.step()
+                losses.append(-elbo.item())
+                step += 1
+        with torch.no_grad():
+            torch.manual_seed(777 + seed)
+            (_, _), (g, v), z, _ = model(Xt, Ut)
+        return np.array(losses, np.float32), float(mean_corr_coef_np(S, z.numpy())), float(mean_corr_coef_np(S, g.numpy()))
+
+    out = dict(n_seeds=np.array(n_seeds), epochs=np.array(epochs), batch=np.array(B))
+    for seed in range(n_seeds):
+        runs = [run(seed, k) for k in range(n_twins + 1)]
+        L = np.stack([r[0] for r in runs])
+        out[f"first_losses{seed}"] = L[0, :20]
+        out[f"epoch_loss{seed}"] = L.reshape(n_twins + 1, epochs, nb).astype(np.float64).mean(2)       # row 0: the run, rows 1..: twins
+        out[f"late_loss{seed}"] = L[:, -200:].astype(np.float64).mean(1)
+        out[f"mcc_sample{seed}"] = np.array([r[1] for r in runs])
+        out[f"mcc_mean{seed}"] = np.array([r[2] for r in runs])
+        print(f"long trace seed {seed}: epoch loss {out[f'epoch_loss{seed}'][0].round(2).tolist()} mcc(sample) "
+              f"{out[f'mcc_sample{seed}'].round(4).tolist()} mcc(mean) {out[f'mcc_mean{seed}'].round(4).tolist()}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "trace_cfg2_long.npz"), **out)
+
+
 def make_trace_twins(n_twins=4):
     """Sensitivity of the REFERENCE trajectory of make_traces: the same runs with the initial parameters moved by ~1e-6
     relative (a few fp32 roundings; same batches, same noise).  1250 Adam steps at lr 1e-2 amplify that; the spread of
@@ -595,6 +648,8 @@ def main():
         return make_trace_twins()
     if len(sys.argv) > 1 and sys.argv[1] == "full_trace":          # full_trace <ivae|btcvae> <seed>
         return make_full_trace(sys.argv[2], int(sys.argv[3]))
+    if len(sys.argv) > 1 and sys.argv[1] == "traces_long":
+        return make_traces_long()
     if len(sys.argv) > 1 and sys.argv[1] == "full_merge":
         return merge_full_traces()
     # family B (models/nets.py:391-486, 548-599)
