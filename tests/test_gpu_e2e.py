@@ -90,3 +90,67 @@ def test_two_epochs_match_reference_trace(dataset):
     # The seed average (the quantity the paper reports, and north_star's "+-0.01 over fixed seeds") against the average
     # over the reference's runs.
     assert abs(np.mean(d_mean)) < 0.01 and abs(np.mean(d_sample)) < 0.01, (d_mean, d_sample)
+
+
+def test_ten_epochs_match_reference_trace(dataset):
+    """The same replay at 10 epochs (6250 steps; tools/make_golden.py traces_long -> tests/golden/trace_cfg2_long.npz: the
+    reference run of every seed plus two twins with the initial parameters moved by 1e-6 relative).  Per seed every epoch's
+    mean loss, the late loss and the final MCC (sampled z and mean g) lie inside the span of the reference's own three
+    trajectories, widened by the widest span any seed shows (three runs sample the spread thinly) plus a floor; the mean
+    over the seeds meets north_star's +-0.01."""
+    S, X, U = dataset
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "trace_cfg2_long.npz"))
+    n_seeds, epochs, B = int(g["n_seeds"]), int(g["epochs"]), int(g["batch"])
+    N = X.shape[0]
+    nb = N // B
+    dev = torch.device("cuda:0")
+    shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
+    steps = epochs * nb
+    params, idx_all, eps_all = [], [], []
+    for seed in range(n_seeds):
+        torch.manual_seed(seed)
+        model = ivae_amd.iVAE(10, 10, 40, n_layers=3, hidden_dim=50, activation='lrelu', slope=.1)
+        params.append(model._flat_params().clone())
+        idx_all.append(torch.cat([trace_batches(seed, e, N, B) for e in range(epochs)]).to(torch.int32))
+        eps = torch.empty(steps, B, 10)
+        for s in range(steps):
+            torch.manual_seed(1_000_000 * (seed + 1) + s)
+            eps[s] = torch.randn(B, 10)
+        eps_all.append(eps)
+    P = torch.stack(params).to(dev)
+    m, v = torch.zeros_like(P), torch.zeros_like(P)
+    Xd = torch.from_numpy(X).to(dev).unsqueeze(0).expand(n_seeds, -1, -1).contiguous()
+    Ud = torch.from_numpy(U).to(dev).unsqueeze(0).expand(n_seeds, -1, -1).contiguous()
+    coef = ops.make_coef(decoder_var=.01, global_batch=B)
+    loss, _ = ops.train_steps(shape, coef, P, m, v, Xd, Ud, torch.stack(idx_all).to(dev), 0, 1e-2,
+                              eps=torch.stack(eps_all).to(dev))
+    loss = loss.cpu().numpy().astype(np.float64)
+    assert np.isfinite(loss).all()
+    epoch_span = np.max([np.ptp(g[f"epoch_loss{sd}"], axis=0) for sd in range(n_seeds)], axis=0)       # (epochs,)
+    ours, refs = {"mcc_sample": [], "mcc_mean": []}, {"mcc_sample": [], "mcc_mean": []}
+    St = torch.from_numpy(S).to(dev)
+    for seed in range(n_seeds):
+        first = g[f"first_losses{seed}"]
+        assert abs(loss[seed, 0] - first[0]) <= 1e-5 * abs(first[0])
+        assert np.abs(loss[seed, :20] - first).max() <= 1e-3 * np.abs(first).max()
+        el = g[f"epoch_loss{seed}"]                                   # (3, epochs)
+        got = loss[seed].reshape(epochs, nb).mean(1)
+        for e in range(epochs):
+            pad = epoch_span[e] + 0.02 * abs(el[0, e]) + 0.05
+            assert el[:, e].min() - pad <= got[e] <= el[:, e].max() + pad, (seed, e, got[e], el[:, e].tolist())
+        late = g[f"late_loss{seed}"]
+        pad = np.ptp(late) + max(np.ptp(g[f"late_loss{sd}"]) for sd in range(n_seeds)) + 0.05
+        assert late.min() - pad <= loss[seed, -200:].mean() <= late.max() + pad, (seed, loss[seed, -200:].mean(), late.tolist())
+        torch.manual_seed(777 + seed)
+        eps_eval = torch.randn(N, 10)
+        ws = ops.Workspace()
+        z = ops.forward(shape, ops.make_coef(decoder_var=.01, global_batch=N), P[seed], Xd[0], Ud[0], eps_eval.to(dev), ws)
+        vals = {"mcc_mean": ivae_amd.mean_corr_coef(St, ws.view("g", N, 10)), "mcc_sample": ivae_amd.mean_corr_coef(St, z)}
+        for key, val in vals.items():
+            ens = g[f"{key}{seed}"]
+            pad = max(np.ptp(g[f"{key}{sd}"]) for sd in range(n_seeds)) + 0.005
+            assert ens.min() - pad <= val <= ens.max() + pad, (seed, key, val, ens.tolist())
+            ours[key].append(val)
+            refs[key].append(ens.mean())
+    for key in ours:
+        assert abs(np.mean(ours[key]) - np.mean(refs[key])) <= 0.01, (key, ours[key], refs[key])
