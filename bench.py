@@ -27,26 +27,24 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 
 
-def synth_dataset(n_models, n_seg, n_per_seg, d, seed, device):
-    """Piecewise-stationary nonlinear-ICA data with the generator semantics of data/data.py:134-304
-    (gaussian sources modulated per segment by L~U(.5,3), 3-layer lrelu mixing with column-normalised
-    uniform matrices), drawn on the device: throughput does not depend on the values."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    N = n_seg * n_per_seg
-    L = torch.rand(n_models, n_seg, 1, d, generator=g, device=device) * 2.5 + 0.5
-    s = torch.randn(n_models, n_seg, n_per_seg, d, generator=g, device=device) * L
-    s = s.reshape(n_models, N, d)
-    A = torch.rand(n_models, d, d, generator=g, device=device) * 2 - 1
-    A = A / A.pow(2).sum(1, keepdim=True).sqrt()
-    x = s
-    for layer in range(3):
-        x = torch.bmm(x, A)
-        if layer < 2:
-            x = torch.where(x > 0, x, 0.1 * x)
-    lab = torch.arange(n_seg, device=device).repeat_interleave(n_per_seg)
-    u = torch.zeros(N, n_seg, device=device)
-    u[torch.arange(N, device=device), lab] = 1
-    return x.contiguous(), u.unsqueeze(0).expand(n_models, N, n_seg).contiguous(), s
+DATA_SEEDS = 4        # datasets drawn by the reference generator per rank; the packed models cycle through them
+
+
+def reference_datasets(n_models, n_seg, n_per_seg, d, first_seed, device):
+    """Inputs of SURVEY.md §8(d): `generate_data(n_per_seg, n_seg, d, d, n_layers=3, seed, prior='gauss',
+    activation='lrelu', repeat_linearity=True)` -- ivae_amd.data's bit-exact restatement of data/data.py:200-304,367-369
+    (sha256-pinned against the reference's arrays, tests/test_data_cpu.py) -- for DATA_SEEDS seeds (about a second of host
+    numpy each), tiled over the packed models: model m trains on dataset m % DATA_SEEDS, with its own initialisation,
+    shuffles and noise.  -> x (n_models, N, d), u (n_models, N, n_seg) one-hot, resident in HBM."""
+    from ivae_amd.data import generate_data
+    xs, us = [], []
+    for k in range(DATA_SEEDS):
+        _, X, U, _, _ = generate_data(n_per_seg, n_seg, d, d, n_layers=3, seed=first_seed + k, prior='gauss',
+                                      activation='lrelu', batch_size=0, repeat_linearity=True)
+        xs.append(torch.from_numpy(np.ascontiguousarray(X, np.float32)))
+        us.append(torch.from_numpy(np.ascontiguousarray(U, np.float32)))
+    pick = torch.arange(n_models) % DATA_SEEDS
+    return torch.stack(xs)[pick].to(device).contiguous(), torch.stack(us)[pick].to(device).contiguous()
 
 
 def flops_per_sample(shape):
@@ -80,34 +78,41 @@ def measured_traffic(kernel, models, steps_per_launch):
     return round(1e3 * models / t["models_per_gpu"] * (t["fixed_kb_per_launch"] + t["kb_per_step"] * steps_per_launch), 1)
 
 
-def cpu_baseline(seconds=10.0):
-    """oracle/torch_ref.Trainer (== the reference's loop: elbo -> backward -> Adam.step) timed on the
-    host, 1 thread and all allotted threads; the better one is reported."""
+def cpu_port_rate(dims, act, B, coef_kw, seconds, decoder_var=.01):
+    """oracle/torch_ref.Trainer (== the reference's loop: elbo -> backward -> Adam.step, a torch-CPU port pinned by the
+    reference fixtures) at one shape, timed on the host at 1 thread and at all allotted threads (the reference is SLOWER
+    multi-threaded at batch 64, SURVEY.md §6, so both are reported and the better one is the baseline).
+    -> {threads: samples/s}, host cores, threads allotted."""
     from oracle import np_ref, torch_ref
-    spec = np_ref.Spec(data_dim=10, latent_dim=10, aux_dim=40, hidden_dim=50, n_layers=3, activation="lrelu")
-    coef = np_ref.Coef(pairwise=False)
+    dd, dl, M, H = dims
+    spec = np_ref.Spec(data_dim=dd, latent_dim=dl, aux_dim=M, hidden_dim=H, n_layers=3, activation=act, decoder_var=decoder_var)
+    coef = np_ref.Coef(**coef_kw)
     g = torch.Generator().manual_seed(0)
-    N, B = 40000, 64
-    x = torch.randn(N, 10, generator=g)
-    u = torch.zeros(N, 40)
-    u[torch.arange(N), torch.arange(N) // 1000] = 1
+    n_b = 8
+    x = torch.randn(n_b, B, dd, generator=g)
+    u = None
+    if M:
+        u = torch.zeros(n_b * B, M)
+        u[torch.arange(n_b * B), torch.randint(0, M, (n_b * B,), generator=g)] = 1
+        u = u.view(n_b, B, M)
     host = len(os.sched_getaffinity(0))
     avail = int(os.environ.get("OMP_NUM_THREADS", "0")) or host
     results = {}
     for nt in sorted({1, min(avail, 16)}):
         torch.set_num_threads(nt)
         tr = torch_ref.Trainer(torch_ref.xavier_params(spec, 0), spec, coef, lr=1e-2)
-        perm = torch.randperm(N, generator=g)
-        for w in range(20):
-            idx = perm[w * B:(w + 1) * B]
-            tr.step(x[idx], u[idx])
+        tr.step(x[0], None if u is None else u[0])                 # warm-up (allocations, thread pool)
         t0, steps = time.perf_counter(), 0
-        while time.perf_counter() - t0 < seconds / 2:
-            for _ in range(50):
-                idx = perm[(steps % 600) * B:(steps % 600 + 1) * B]
-                tr.step(x[idx], u[idx])
-                steps += 1
+        while time.perf_counter() - t0 < seconds / 2 or steps < 2:
+            tr.step(x[steps % n_b], None if u is None else u[steps % n_b])
+            steps += 1
         results[nt] = steps * B / (time.perf_counter() - t0)
+    return results, host, avail
+
+
+def cpu_baseline(seconds=10.0):
+    """The headline workload on the host cores: ONE model (the reference trains one model per process), batch 64."""
+    results, host, avail = cpu_port_rate((10, 10, 40, 50), "lrelu", 64, dict(pairwise=False), seconds)
     best = max(results, key=results.get)
     return {"value": round(results[best], 1), "unit": "samples/s", "cores": best, "host_cores": host,
             "threads_allotted": avail, "by_threads": {str(k): round(v, 1) for k, v in results.items()}, "kind": "port",
@@ -128,7 +133,7 @@ OTHER_CONFIGS = [
 ]
 
 
-def other_config_lines(dev, steps=200):
+def other_config_lines(dev, steps=200, cpu=True):
     """fwd+bwd[+pairwise]+Adam through ivae_elbo_adam_steps (one library call for all steps), HIP events on the launch
     stream around the call; FLOPs per SURVEY.md §8(d): MLP part + 2.5 * 8 * B * d per sample for the pairwise terms."""
     from ivae_amd import ops
@@ -161,11 +166,102 @@ def other_config_lines(dev, steps=200):
         fl = flops_per_sample(shape) + (int(2.5 * 8 * B * dl) if ck.get("pairwise") else 0)
         tf = fl * B / dt / 1e12
         assert bool(torch.isfinite(loss).all()), key
-        out.append({"config": key, "workload": workload, "impl": "shape-generic kernels, one model", "value": round(B / dt, 1),
-                    "unit": "samples/s", "ms_per_step": round(1e3 * dt, 5), "steps": steps,
-                    "roofline": {"bound": "mfma", "achieved": round(tf, 4), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": round(tf / FP32_PEAK_TFLOPS, 5), "algorithmic_flops_per_sample": fl}})
+        line = {"config": key, "workload": workload, "impl": "shape-generic kernels, one model", "value": round(B / dt, 1),
+                "unit": "samples/s", "ms_per_step": round(1e3 * dt, 5), "steps": steps,
+                "roofline": {"bound": "mfma", "achieved": round(tf, 4), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tf / FP32_PEAK_TFLOPS, 5), "algorithmic_flops_per_sample": fl}}
+        if ck.get("pairwise"):
+            # The B x B x d terms are not a contraction: per (i, j, k) the kernels issue about 40 VALU and 3.2 v_exp_f32
+            # instructions; at one vector instruction per 4 cycles per SIMD (8 for the transcendental unit)
+            # that is 1024 SIMDs x 2.4 GHz / (40 * 4 + 3.2 * 8) cycles = 13.2 T elements/s at best.
+            el = B * B * dl
+            line["pairwise_roofline"] = {"bound": "valu/exp", "unit": "T (i,j,k) elements/s", "peak": 13.2,
+                                         "elements_per_step": el,
+                                         "note": "instruction-issue roof of the pairwise kernels; the mfma line above prices "
+                                                 "the whole step by the MLP FLOPs only"}
+        if cpu:
+            res, host, avail = cpu_port_rate((dd, dl, M, H), act, B, {k: v for k, v in ck.items() if k != "decoder_var"} | {"N": float(N)},
+                                             4.0, decoder_var=ck.get("decoder_var", .01))
+            best = max(res, key=res.get)
+            line["cpu_baseline"] = {"value": round(res[best], 1), "unit": "samples/s", "cores": best, "host_cores": host,
+                                    "by_threads": {str(k): round(v, 1) for k, v in res.items()}, "kind": "port",
+                                    "sample": "oracle/torch_ref.Trainer at this shape, ~2 s per thread setting"}
+            line["x_cpu_baseline"] = round(B / dt / res[best], 1)
+        out.append(line)
     return out
+
+
+def run_dp(args, rank, world, dev):
+    """--mode dp: BASELINE configs[3] -- ONE large-batch iVAE (d=20, 200 segments x 5000 samples, batch 4096), data-parallel
+    over the ranks (north_star's second multi-GPU mode; strong scaling: the global batch is fixed, rank r takes
+    row_range(batch, r, N) of it), per step ivae_elbo_fwd_bwd on the shard, ONE all-reduce(sum) of [gradient | loss] over
+    RCCL, the identical fused Adam on every rank."""
+    import torch.distributed as dist
+    from ivae_amd import ops
+    from ivae_amd.dist import DataParallelTrainer, row_range
+    from ivae_amd.trainer import init_packed_params
+    shape = ops.ModelShape(20, 20, 200, 50, 3, "lrelu", .1)
+    B, N = 4096, 200 * 5000
+    lo, hi = row_range(B, rank, world)
+    g = torch.Generator(device=dev).manual_seed(1)           # same stream on every rank: identical global batches
+    params = init_packed_params(shape, 1, 0, dev)[0].contiguous()
+    tr = DataParallelTrainer(shape, params, decoder_var=.01, lr=1e-3)
+    nb = 8                                                   # a few resident global batches, cycled
+    xs = torch.randn(nb, B, 20, generator=g, device=dev)
+    lab = torch.randint(0, 200, (nb, B), generator=g, device=dev)
+    us = torch.zeros(nb, B, 200, device=dev).scatter_(2, lab.unsqueeze(-1), 1.)
+    es = torch.randn(nb, B, 20, generator=g, device=dev)
+
+    def run(n):
+        for s_ in range(n):
+            i = s_ % nb
+            loss, _ = tr.step(xs[i, lo:hi], us[i, lo:hi], es[i, lo:hi], B, N=float(N))
+        return loss
+
+    run(max(args.warmup, 10))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    loss = run(args.steps)
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    fps = flops_per_sample(shape)
+    gpu_s = 1e-3 * e0.elapsed_time(e1) / args.steps
+    tf = fps * B / gpu_s / 1e12
+    out = {"metric": "iVAE train samples/sec (fwd+bwd+Adam), data-parallel large batch (BASELINE configs[3])",
+           "value": round(args.steps * B / dt, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+           "warmup": max(args.warmup, 10), "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3]: iVAE d=20, 200 segments, 3-layer lrelu MLPs hidden 50, global batch "
+                                  "4096, plain ELBO + Adam", "global_batch": B, "rows_per_rank": hi - lo,
+                      "collective": ("none (one rank)" if world == 1 else
+                                     "RCCL all-reduce(sum) of [gradient | loss] (%d floats) per step, world size %d" % (
+                                         params.numel() + 1, world)),
+                      "backend": "nccl" if world > 1 else None, "impl": "shape-generic kernels (k_chain, k_wgrad, k_reduce+Adam)",
+                      "parallelism": "dp%d" % world},
+           "final_loss": round(float(loss[0]), 3),
+           "roofline": {"bound": "mfma", "kernel": "one step's launches on rank 0 (HIP events around the K steps, collective included)",
+                        "achieved": round(tf / world, 4), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s per GPU",
+                        "frac": round(tf / world / FP32_PEAK_TFLOPS, 5), "traffic": None,
+                        "algorithmic_flops_per_sample": fps}}
+    if world == 1 and not args.no_cpu_baseline:
+        res, host, avail = cpu_port_rate((20, 20, 200, 50), "lrelu", B, dict(pairwise=False), 8.0)
+        best = max(res, key=res.get)
+        out["cpu_baseline"] = {"value": round(res[best], 1), "unit": "samples/s", "cores": best, "host_cores": host,
+                               "by_threads": {str(k): round(v, 1) for k, v in res.items()}, "kind": "port",
+                               "sample": "oracle/torch_ref.Trainer at this shape and batch, ~4 s per thread setting"}
+    print(json.dumps(out))
 
 
 def spawn_ranks(n):
@@ -197,6 +293,10 @@ def main():
                     help="untimed device warm-up before the W warmup steps: training steps on a scratch copy of the "
                          "models, so that clocks and caches are at their steady state when the K timed steps start")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["pack", "dp"], default="pack",
+                    help="pack (default): the headline -- independent packed models per GPU, no collective (weak scaling); "
+                         "dp: BASELINE configs[3], one large-batch model data-parallel over the GPUs with an RCCL gradient "
+                         "all-reduce per step (strong scaling)")
 
     ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
@@ -215,12 +315,18 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    if args.mode == "dp":
+        run_dp(args, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     from ivae_amd import ops
     from ivae_amd.trainer import FusedPackedTrainer, PackedTrainer
 
     shape = ops.ModelShape(10, 10, 40, 50, 3, "lrelu", .1)
     M, B = args.models, args.batch
-    x, u, _ = synth_dataset(M, 40, 1000, 10, seed=1 + rank, device=dev)
+    x, u = reference_datasets(M, 40, 1000, 10, first_seed=1 + DATA_SEEDS * rank, device=dev)
     fused = args.impl == "fused"
     if fused:
         tr = FusedPackedTrainer(shape, n_models=M, batch=B, lr=1e-2, seed=rank, device=dev)
@@ -251,7 +357,7 @@ def main():
     advance(args.warmup, False)
     if fused:      # the events of the timed launches exist before the timed region starts
         tr.prepare_timing((args.steps + tr.CHUNK - 1) // tr.CHUNK + 1)
-        tr.prepare_indices(args.steps)         # (the next launch's row indices: input preparation, like the data itself)
+        tr.prepare_indices(args.steps)         # (a run's first permutation: input preparation, like the data itself)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -288,7 +394,7 @@ def main():
                        "models_per_gpu": M, "batch": B, "impl": tr.impl, "rng": tr.rng,
                        "device_warmup_ms": args.spinup_ms,
                        "parallelism": "independent model sets per GPU, no collective"},
-            "steps_per_s_per_model": round(args.steps / dt, 1),
+            "per_model": {"steps_per_s": round(args.steps / dt, 1), "samples_per_s": round(args.steps * B / dt, 1)},
             "final_mean_loss": round(loss, 3),
             "roofline": {"bound": "mfma", "kernel": tr.dominant_kernel, "achieved": round(achieved, 4),
                          "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 5),
@@ -297,10 +403,25 @@ def main():
                          "avg_launch_us": round(kern_s * 1e6, 2),
                          "steps_per_launch": steps_per_launch, "algorithmic_flops_per_launch": algo_flops},
         }
+        if fused:
+            # MFMA slots actually issued: 608.5 v_mfma_f32_16x16x4_f32 per wave and step (PMC SQ_INSTS_MFMA,
+            # profiles/r2_pmc_instruction_mix_fused.txt; the tiling pads 50 -> 64 columns and 10 -> 16), 8 waves, 2048 FLOP each
+            executed = 608.5 * 8 * 2048 * M * steps_per_launch
+            out["roofline"]["executed_flops_per_launch"] = executed
+            out["roofline"]["executed_frac"] = round(executed / kern_s / 1e12 / FP32_PEAK_TFLOPS, 5)
+            out["roofline"]["executed_note"] = "matrix-pipe occupancy: padded MFMA FLOPs / peak; frac prices algorithmic FLOPs only"
+            out["config"]["input_pipeline"] = ("FusedPackedTrainer.run, the code path training uses: a launch points into the "
+                                               "epoch's device-side permutation table (no per-launch index slice); the "
+                                               "permutation of each new epoch is drawn inside the timed region")
+            out["config"]["datasets"] = "%d datasets from the bit-exact host generator (seeds %d..%d), tiled over the models" % (
+                DATA_SEEDS, 1, DATA_SEEDS)
         if world == 1 and not args.no_other_configs:
-            out["other_configs"] = other_config_lines(dev)
+            out["other_configs"] = other_config_lines(dev, cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["per_model"]["x_cpu_baseline"] = round(out["per_model"]["samples_per_s"] / out["cpu_baseline"]["value"], 2)
+            out["per_model"]["note"] = ("one packed model against the CPU baseline's one model: the like-for-like ratio; "
+                                        "`value` is %d such models" % M)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

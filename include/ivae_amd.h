@@ -170,7 +170,9 @@ int ivae_elbo_adam_steps(const IvaeDims* dims, const IvaeCoef* coef, const IvaeC
  * caller's choice of indices, runners/ivae.py:25).  Only shapes for which
  * ivae_train_steps_supported() returns 1 (3 layers, lrelu, batch 64, plain ELBO, LDS fit).
  *   params/exp_avg/exp_avg_sq (n_models, P) in/out;  x_data (n_models, n_data, data_dim);
- *   u_data (n_models, n_data, aux_dim) or NULL;  batch_idx (n_models, n_steps, 64) int32 rows;
+ *   u_data (n_models, n_data, aux_dim) or NULL;  batch_idx (n_models, n_steps, 64) int32 rows -- or, with
+ *   batch_idx_stride != 0, model m's table starts batch_idx_stride ints after model m-1's (the call may then point into
+ *   an epoch's whole permutation table, (n_models, n_data), at the first step it is to run: no per-call slice);
  *   eps (n_models, n_steps, 64, latent_dim) or NULL -> in-kernel Philox4x32-10 + Box-Muller (seed);
  *   step0 = Adam steps already taken;  loss_out (n_models, n_steps);
  *   z_out (n_models, 64, latent_dim) of the LAST step, or NULL;
@@ -186,7 +188,7 @@ int ivae_train_steps_supported(const IvaeDims* dims);
 int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef,
                      float* params, float* exp_avg, float* exp_avg_sq,
                      const float* x_data, const float* u_data, int64_t n_data,
-                     const int32_t* batch_idx, const float* eps, uint64_t seed,
+                     const int32_t* batch_idx, int64_t batch_idx_stride, const float* eps, uint64_t seed,
                      int32_t n_steps, int64_t step0,
                      double lr, const double* model_lr, double beta1, double beta2, double adam_eps,
                      float* loss_out, float* z_out, float* z_steps, void* stream);

@@ -64,7 +64,7 @@ def lib():
     L.ivae_elbo_adam_steps.argtypes = [pd, pc, pc, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int64, f64, C.POINTER(C.c_double), f64, f64,
                                        f64, vp, vp, vp, vp, C.c_size_t, vp]
     L.ivae_train_steps_supported.argtypes = [pd]
-    L.ivae_train_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, C.c_int64, vp, vp, C.c_uint64, C.c_int32, C.c_int64,
+    L.ivae_train_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, C.c_int64, vp, C.c_int64, vp, C.c_uint64, C.c_int32, C.c_int64,
                                    f64, C.POINTER(C.c_double), f64, f64, f64, vp, vp, vp, vp]
     L.ivae_debug_fault_inject.argtypes = [C.c_int32]
     L.ivae_corr_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_size_t)]

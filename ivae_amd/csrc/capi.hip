@@ -211,9 +211,9 @@ int ivae_debug_fault_inject(int32_t mask) {
 
 int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
                      const float* x_data, const float* u_data, int64_t n_data, const int32_t* batch_idx,
-                     const float* eps, uint64_t seed, int32_t n_steps, int64_t step0, double lr, const double* model_lr,
-                     double beta1, double beta2, double adam_eps, float* loss_out, float* z_out, float* z_steps,
-                     void* stream) {
+                     int64_t batch_idx_stride, const float* eps, uint64_t seed, int32_t n_steps, int64_t step0, double lr,
+                     const double* model_lr, double beta1, double beta2, double adam_eps, float* loss_out, float* z_out,
+                     float* z_steps, void* stream) {
     int rc = ivae_check_dims(dims);
     if (rc) return rc;
     if ((rc = check_coef(dims, coef))) return rc;
@@ -222,6 +222,8 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, 
         return IVAE_E_NULLPTR;
     if (n_steps <= 0 || n_data <= 0 || step0 < 0) return IVAE_E_BADDIMS;
     if (n_data > 0x7fffffff) return IVAE_E_TOOLARGE;          // row indices are int32
+    if (batch_idx_stride == 0) batch_idx_stride = (int64_t)n_steps * 64;
+    if (batch_idx_stride < (int64_t)n_steps * 64) return IVAE_E_BADDIMS;
     if (model_lr) {           // the step table is formed for `lr`; a model's own rate enters as a factor on it
         if (!(lr != 0.0)) return IVAE_E_BADDIMS;
     }
@@ -250,7 +252,8 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, 
             A.params = params + m * P; A.exp_avg = exp_avg + m * P; A.exp_avg_sq = exp_avg_sq + m * P;
             A.x_data = x_data + m * n_data * dd;
             A.u_data = u_data ? u_data + m * n_data * da : nullptr;
-            A.batch_idx = batch_idx + m * n_steps * 64;
+            A.batch_idx = batch_idx + m * (size_t)batch_idx_stride;
+            A.idx_stride = batch_idx_stride;
             A.eps = eps ? eps + m * n_steps * 64 * dl : nullptr;
             A.loss_out = loss_out + m * n_steps;
             A.z_steps = z_steps ? z_steps + m * n_steps * 64 * dl : nullptr;

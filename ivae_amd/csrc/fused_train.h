@@ -12,7 +12,8 @@ struct FusedArgs {
     float* exp_avg_sq;        // (n_models, P) in/out
     const float* x_data;      // (n_models, n_data, data_dim)
     const float* u_data;      // (n_models, n_data, aux_dim) or null
-    const int* batch_idx;     // (n_models, n_steps, 64)
+    const int* batch_idx;     // model m's rows of step s: batch_idx[m * idx_stride + s * 64 + 0..63]
+    int64_t idx_stride;       // ints between the tables of consecutive models
     const float* eps;         // (n_models, n_steps, 64, latent) or null -> Philox(seed)
     float* loss_out;          // (n_models, n_steps)
     float* z_out;             // (n_models, 64, latent) of the last step, or null

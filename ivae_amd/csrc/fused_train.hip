@@ -67,10 +67,22 @@ __device__ unsigned long long* g_ft_prof = nullptr;
             g_ft_prof[(size_t)s * FT_NSTAMP + 64 + (threadIdx.x >> 3) + (i)] = t_;                 \
         }                                                                                          \
     } while (0)
+// in-stream stamps (no wait at the stamp: the counter is read into scalar registers and stored by TSTORE at the end)
+#define TDECL unsigned long long tq_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TMARK(i) asm volatile("s_memtime %0" : "=s"(tq_[i])::"memory")
+#define TSTORE(step, base)                                                                         \
+    do {                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256) && g_ft_prof)              \
+            for (int i_ = 0; i_ < 8; ++i_) g_ft_prof[(size_t)(step) * FT_NSTAMP + 64 + (threadIdx.x >> 3) + (base) + i_] = tq_[i_]; \
+    } while (0)
 #else
 #define STAMP(i)
 #define STAMPW(i)
 #define STAMPB(i)
+#define TDECL
+#define TMARK(i)
+#define TSTORE(step, base)
 #endif
 
 #define FT_THREADS 512
@@ -366,7 +378,9 @@ __device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float*
 // input-gradient epilogue, which needs accd complete -- is issued between the weight-gradient MFMAs.
 template <int NS, int N, int KS, class F>
 __device__ __forceinline__ void mm_dgrad_wgrad(const float* yrow, const float* wcol, const float* ycol, int sy, const float* xcol,
-                                               int sx, int q, f32x4 (&accd)[2], f32x4 (&accw)[2], F&& fill) {
+                                               int sx, int q, f32x4 (&accd)[2], f32x4 (&accw)[2], F&& fill, int prof_step = -1) {
+    TDECL;
+    TMARK(0);
     constexpr int G = (NS - 4) / 8, PF = FT_PF, R = PF + 1;
     static_assert(NS == 8 * G + 4 && G >= 2, "contraction lengths are 4*odd, >= 20");
     f32x2 a[R], b0[R], b1[R], bt = {0.f, 0.f};
@@ -421,6 +435,8 @@ __device__ __forceinline__ void mm_dgrad_wgrad(const float* yrow, const float* w
         if (t == G - 2) wfetch(0);
         if (t == G - 1) wfetch(1);
         SCHED_FENCE();
+        if (t == 0) TMARK(1);
+        if (t == 3) TMARK(2);
         accd[0] = mfma4(a[cur].x, b0[cur].x, accd[0]);
         accd[1] = mfma4(a[cur].x, b0[cur].y, accd[1]);
         accd[0] = mfma4(a[cur].y, b1[cur].x, accd[0]);
@@ -429,17 +445,23 @@ __device__ __forceinline__ void mm_dgrad_wgrad(const float* yrow, const float* w
     }
     accd[0] = mfma4(at, bt.x, accd[0]);
     accd[1] = mfma4(at, bt.y, accd[1]);
+    TMARK(3);
 #pragma unroll
     for (int t = 0; t < WG_G; ++t) {
         const int cur = t % WR;
         wfetch(t + 2);
         SCHED_FENCE();
+        if (t == 4) TMARK(4);
 #pragma unroll
         for (int i = 0; i < 2; ++i) { accw[0] = mfma4(wa[cur][i], wb[cur][i].x, accw[0]); accw[1] = mfma4(wa[cur][i], wb[cur][i].y, accw[1]); }
         fill(t);
         interleave_mfma<4, 5, 1>();
         SCHED_FENCE();
     }
+    TMARK(5);
+#ifdef FT_PROF
+    if (prof_step >= 0) TSTORE(prof_step, 0);
+#endif
 }
 
 // single tile: operands of all 16 k-steps read up front (32 registers)
@@ -656,7 +678,7 @@ __device__ __forceinline__ void wgrad_pair(const float* dY, int sy, const float*
 // The input-gradient epilogue (mask from h1, read before the first product) is issued between the weight-gradient MFMAs.
 template <class C, bool ROWGUARD>
 __device__ __forceinline__ void dgrad_wgrad_hidden(const float* dY, const float* W, const float* h, float* out, float* stage,
-                                                   float slope, int w) {
+                                                   float slope, int w, int prof_step = -1) {
     constexpr int ST = C::ST, KS = C::KS_H, H = C::H;
     const int lane = opaque_lane();
     const int c = lane & 15, q = lane >> 4;
@@ -678,7 +700,7 @@ __device__ __forceinline__ void dgrad_wgrad_hidden(const float* dY, const float*
             const float v1 = in1 ? accd[1][t] * (hm[t].y > 0.f ? 1.f : slope) : 0.f;
             st2(orow + t * ST, v0, v1);
         }
-    });
+    }, prof_step);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = 16 * rt + 4 * q + r;       // rows >= H land in the tail of the (64-row) stage tile unless guarded
@@ -904,7 +926,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
     float* gV = A.exp_avg_sq + (size_t)model * C::NPARAM;
     const float* xd = A.x_data + (size_t)model * A.n_data * DD;
     const float* ud = C::HAS_U ? A.u_data + (size_t)model * A.n_data * M : A.x_data;
-    const int* idxp = A.batch_idx + ((size_t)model * A.n_steps_total + A.step_begin) * FT_B;
+    const int* idxp = A.batch_idx + (size_t)model * A.idx_stride + (size_t)A.step_begin * FT_B;
     const float slope = A.slope;
     const float wB = 1.f / (float)FT_B;
 
@@ -1177,8 +1199,15 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 }, LAMBDA { ADAM(L_F0, stF0); if (w < 4) restore_rows<C>(s1, T4, rt); });
         BAR(13);
         // ---- G2: d1g -> T2; layer-2 gradient -> T1; Adam(G2)
+#ifdef FT_PROF
+        dgrad_wgrad_hidden<C, false>(T0, arena + C::off_of(L_G1), T4, T2, T1, slope, w, s);
+        STAMPB(8);
+        ADAM(L_G2, sZ);
+        STAMPB(9);
+#else
         dgrad_wgrad_hidden<C, false>(T0, arena + C::off_of(L_G1), T4, T2, T1, slope, w);
         ADAM(L_G2, sZ);
+#endif
         BAR(14);
         // ---- G1: layer-1 gradient -> T0; Adam(G1); h2v -> T4
         WGRAD_ADAM(H, KS_E0, C::KIN, T2, ST, T3, ST, T0, L_G1, T1);

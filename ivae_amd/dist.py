@@ -60,30 +60,26 @@ class DataParallelELBO:
     make the result equal to the single-GPU full-batch result.
 
     `backend` is the module that launches the kernels (`ivae_amd.ops`; tests substitute an oracle-backed double to
-    exercise the exchange logic on CPU ranks).  `stage_on_cpu` moves collective payloads through host memory for
-    process groups that cannot take device tensors (gloo with ROCm tensors)."""
+    exercise the exchange logic on CPU ranks).  The two collectives are methods (`_all_reduce`, `_all_gather_rows`) so that
+    a test double can route them differently (tests/test_gpu_dist.py stages them through host memory for gloo).
 
-    def __init__(self, shape, decoder_var, group=None, backend=None, stage_on_cpu=False):
+    The tensors `fwd_bwd` returns as loss and gradient are VIEWS of one persistent buffer (the message of the step's one
+    collective): they hold this step's values until the next call overwrites them -- clone what must outlive the step."""
+
+    def __init__(self, shape, decoder_var, group=None, backend=None):
         if backend is None:
             from . import ops as backend
         self.be = backend
         self.shape = shape
         self.decoder_var = float(decoder_var)
         self.group = group
-        self.stage = stage_on_cpu
         self.rank, self.world = _world(group)
         self.ws = backend.Workspace()
         self._gl = None          # [gradient | loss]: written by the kernels, all-reduced as one message
 
     # -- collectives -----------------------------------------------------------------
     def _all_reduce(self, t):
-        if self.world == 1:
-            return t
-        if self.stage:
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-        else:
+        if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -93,19 +89,17 @@ class DataParallelELBO:
             return t
         sizes = [row_range(global_batch, r, self.world) for r in range(self.world)]
         cap = max(hi - lo for lo, hi in sizes)
-        src = t.cpu() if self.stage else t
-        pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=src.device)
-        pad[:t.shape[0]] = src
+        pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
         parts = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(parts, pad, group=self.group)
-        out = torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
-        return out.to(t.device)
+        return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
 
     # -- one step ---------------------------------------------------------------------
     def fwd_bwd(self, params, x, u, eps, global_batch, a=1., b=1., c=1., d=1., N=1., pairwise=False):
         """x, u, eps: this rank's rows [row_range(global_batch, rank, world)) of the global batch.
         Returns (loss of the whole batch, z of the local rows, flat gradient of the whole batch); loss and
-        gradient are identical on every rank."""
+        gradient are identical on every rank, and are views of a buffer the NEXT call overwrites."""
         be, sh = self.be, self.shape
         lo, hi = row_range(global_batch, self.rank, self.world)
         if x.shape[0] != hi - lo:
@@ -142,11 +136,12 @@ class DataParallelELBO:
 class DataParallelTrainer:
     """zero_grad -> elbo -> backward -> Adam.step (runners/ivae.py:75-91, wrappers.py:64-70) for one model whose
     batch is split by rows over the ranks.  Parameters and Adam moments are replicated; every rank applies the
-    same update to the same all-reduced gradient, so replicas stay bit-identical without a broadcast."""
+    same update to the same all-reduced gradient, so replicas stay bit-identical without a broadcast.
+    `step` returns (loss, z); the loss is a view of the exchange buffer, valid until the next step (clone to keep it)."""
 
     def __init__(self, shape, params, decoder_var=.01, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, group=None,
-                 backend=None, stage_on_cpu=False):
-        self.dp = DataParallelELBO(shape, decoder_var, group, backend, stage_on_cpu)
+                 backend=None, elbo=None):
+        self.dp = elbo if elbo is not None else DataParallelELBO(shape, decoder_var, group, backend)
         self.params = params
         self.exp_avg = torch.zeros_like(params)
         self.exp_avg_sq = torch.zeros_like(params)

@@ -315,18 +315,31 @@ def train_steps_supported(shape, batch):
 
 
 def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_idx, step0, lr, eps=None, seed=0,
-                beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False, want_z_steps=False):
+                beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False, want_z_steps=False, table_steps=None):
     """ivae_train_steps: n_steps fused (elbo -> backward -> Adam) iterations for all packed models.
     params/exp_avg/exp_avg_sq (n_models, P) are updated in place; batch_idx (n_models, n_steps, B) int32.
     `lr`: one learning rate, or a sequence of n_models of them (packed runs with their own schedulers).
     Returns (loss (n_models, n_steps), z of the last step or None); with want_z_steps the second value is the
-    (n_models, n_steps, B, latent) z of every step instead."""
+    (n_models, n_steps, B, latent) z of every step instead.
+    table_steps=(first, n): batch_idx is instead an epoch's whole (n_models, rows) int32 permutation table and the call runs
+    the n steps whose rows start at column first * 64 of every model's row (no slice is cut: the library takes the
+    table's row stride)."""
     for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (x_data, "x_data")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError(f"{n} must be a contiguous float32 ROCm tensor")
-    if batch_idx.dtype != torch.int32 or not batch_idx.is_contiguous() or batch_idx.dim() != 3:
-        raise TypeError("batch_idx must be a contiguous int32 (n_models, n_steps, batch) tensor")
-    n_models, n_steps, B = batch_idx.shape
+    idx_stride, idx_off = 0, 0
+    if table_steps is not None:
+        if batch_idx.dtype != torch.int32 or not batch_idx.is_contiguous() or batch_idx.dim() != 2:
+            raise TypeError("with table_steps, batch_idx must be a contiguous int32 (n_models, rows) table")
+        first, n_steps = (int(v) for v in table_steps)
+        n_models, B, idx_stride = batch_idx.shape[0], 64, batch_idx.shape[1]
+        if first < 0 or n_steps <= 0 or (first + n_steps) * B > idx_stride:
+            raise ValueError("table_steps reaches past the table's rows")
+        idx_off = first * B * 4
+    else:
+        if batch_idx.dtype != torch.int32 or not batch_idx.is_contiguous() or batch_idx.dim() != 3:
+            raise TypeError("batch_idx must be a contiguous int32 (n_models, n_steps, batch) tensor")
+        n_models, n_steps, B = batch_idx.shape
     if params.shape[0] != n_models or x_data.shape[0] != n_models:
         raise ValueError("params / x_data / batch_idx disagree on n_models")
     model_lr = None
@@ -352,7 +365,8 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
         zs = (torch.empty(n_models, n_steps, B, shape.latent_dim, dtype=torch.float32, device=dev)
               if want_z_steps else None)
         check(_lib.lib().ivae_train_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
-                                          _ptr(x_data), _ptr(u_data), x_data.shape[1], _ptr(batch_idx), _ptr(eps),
+                                          _ptr(x_data), _ptr(u_data), x_data.shape[1],
+                                          C.c_void_p(batch_idx.data_ptr() + idx_off), idx_stride, _ptr(eps),
                                           int(seed), n_steps, int(step0), float(lr), model_lr, float(beta1), float(beta2),
                                           float(adam_eps), _ptr(loss), _ptr(z), _ptr(zs), _stream(dev)),
               "ivae_train_steps")

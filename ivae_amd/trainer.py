@@ -161,7 +161,7 @@ class PackedTrainer:
 class FusedPackedTrainer:
     """Fused-kernel implementation: `ivae_train_steps` advances every packed model by up to 128
     steps per launch (parameters in LDS, Adam moments in registers, in-kernel Philox noise).
-    Host work per launch: one slice of the epoch's device-side permutation."""
+    Host work per launch: none beyond the call (a launch points into the epoch's device-side permutation table)."""
     impl = "fused persistent kernel (k_train_steps)"
     rng = "in-kernel Philox4x32-10 + Box-Muller"
     dominant_kernel = "k_train_steps"
@@ -188,6 +188,10 @@ class FusedPackedTrainer:
         self.u = u.contiguous() if u is not None else None
         self._perm = None
 
+    # -- input pipeline: ONE device-side permutation table per epoch; a launch points into it (batch_idx_stride of
+    #    ivae_train_steps), so no per-launch index slice exists.  (Cutting slices or drawing the next epoch's permutation on
+    #    a side stream WHILE a launch runs was measured and dropped: the kernel owns every CU, and whatever shares them
+    #    delays some workgroups' start -- 125-step launches 4.12 -> 4.85 ms.)
     def _reshuffle(self):
         N = self.x.shape[1]
         self._nb = N // self.B                                      # drop_last=True (runners/ivae.py:25)
@@ -203,22 +207,10 @@ class FusedPackedTrainer:
         torch.cuda.synchronize(self.dev)
         self._ev_pool = pool
 
-    def _take_indices(self, k):
-        """(n_models, k, batch) row indices of the next k steps; the slice prepare_indices made ahead, if it is this one."""
-        pre = getattr(self, "_idx_ready", None)
-        self._idx_ready = None
-        if pre is not None and pre[0] == self._cursor and pre[1] == k and pre[2] is self._perm:
-            return pre[3]
-        return self._perm[:, self._cursor * self.B:(self._cursor + k) * self.B].reshape(self.M, k, self.B).contiguous()
-
     def prepare_indices(self, n_steps):
-        """Data-loader prefetch: cut the index slice of the next launch now (a small device copy), so that it is not
-        waited for in front of that launch."""
+        """Draw the epoch's permutation now if the next launch would have to (kept for callers that time launches)."""
         if self._perm is None or self._cursor >= self._nb:
             self._reshuffle()
-        k = min(n_steps, self.CHUNK, self._nb - self._cursor)
-        self._idx_ready = None
-        self._idx_ready = (self._cursor, k, self._perm, self._take_indices(k))
 
     def _event(self):
         pool = getattr(self, "_ev_pool", None)
@@ -231,12 +223,12 @@ class FusedPackedTrainer:
             if self._perm is None or self._cursor >= self._nb:
                 self._reshuffle()
             k = min(n_steps, self.CHUNK, self._nb - self._cursor)
-            idx = self._take_indices(k)
             if timed:
                 e0, e1 = self._event(), self._event()
                 e0.record()
             loss, z = ops.train_steps(self.shape, self.coef, self.params, self.exp_avg, self.exp_avg_sq, self.x, self.u,
-                                      idx, self.t, self.lr, seed=self.seed, want_z=want_z and k == n_steps)
+                                      self._perm, self.t, self.lr, seed=self.seed, want_z=want_z and k == n_steps,
+                                      table_steps=(self._cursor, k))
             if timed:
                 e1.record()
                 self._ev.append((e0, e1))

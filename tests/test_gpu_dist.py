@@ -47,7 +47,19 @@ def _worker(rank, world, port, name, out, backend="gloo"):
         lo, hi = row_range(B, rank, world)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
         co = c.coef(0)
-        dp = DataParallelELBO(shape, s.decoder_var, stage_on_cpu=not rccl)
+        class HostStagedELBO(DataParallelELBO):
+            """Test double: gloo cannot take ROCm tensors, so the two collectives go through host memory."""
+
+            def _all_reduce(self, t_):
+                h = t_.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                t_.copy_(h)
+                return t_
+
+            def _all_gather_rows(self, t_, global_batch):
+                return super()._all_gather_rows(t_.cpu(), global_batch).to(t_.device)
+
+        dp = (DataParallelELBO if rccl else HostStagedELBO)(shape, s.decoder_var)
         loss, z, grads = dp.fwd_bwd(t(_flat(c.params, s.param_names())), t(x[lo:hi]), t(u[lo:hi]) if s.aux_dim else None,
                                     t(eps[lo:hi]), B, a=co.a, b=co.b, c=co.c, d=co.d, N=co.N, pairwise=co.pairwise)
         torch.cuda.synchronize()

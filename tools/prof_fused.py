@@ -55,3 +55,10 @@ for wv, base, names in (("wave0", 32, names0), ("wave4", 48, names4)):
 print("wave0 g L1: product took", int((raw[:, 32 + 9] - raw[:, 32 + 1]).mean()), "epilogue", int((raw[:, 32 + 2] - raw[:, 32 + 9]).mean()))
 print("stage barrier released (STAMP 8) @", int((raw[:, 8] - raw[:, 32]).mean()))
 
+
+# in-stream stamps of the G2 phase (dgrad -> wgrad stream), waves 0 and 4, cycles since the phase's barrier release (stamp 13)
+for wv, base in (("wave0", 64), ("wave4", 96)):
+    rel = lambda i: int((raw[:, base + i] - raw[:, 13]).mean())
+    print(wv, "G2 stream: entry", rel(0), "first MFMA", rel(1), "4th dgrad group", rel(2), "dgrad MFMAs issued", rel(3),
+          "5th wgrad group", rel(4), "wgrad MFMAs issued", rel(5), "stores done", rel(8), "adam done", rel(9),
+          "| barrier14 @", int((raw[:, 14] - raw[:, 13]).mean()))
