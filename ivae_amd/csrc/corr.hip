@@ -25,7 +25,19 @@ __global__ __launch_bounds__(256) void k_corr_sums(const float* __restrict__ x, 
     double acc = 0.0;
     if (sub < nsub) {
         const float* src = c < d ? x + c : y + (c - d);
-        for (int64_t r = (int64_t)blockIdx.x * nsub + sub; r < n; r += (int64_t)gridDim.x * nsub) acc += (double)src[r * d];
+        // eight rows' loads in flight per thread (a dependent one-load-per-iteration walk is bound by memory latency:
+        // 0.97 ms at n = 10^6, d = 20); the sum keeps its row order
+        const int64_t stride = (int64_t)gridDim.x * nsub;
+        for (int64_t r = (int64_t)blockIdx.x * nsub + sub; r < n; r += 8 * stride) {
+            float vals[8];
+#pragma unroll
+            for (int u_ = 0; u_ < 8; ++u_) {
+                const int64_t rr = r + u_ * stride;
+                vals[u_] = rr < n ? src[rr * d] : 0.f;
+            }
+#pragma unroll
+            for (int u_ = 0; u_ < 8; ++u_) acc += (double)vals[u_];
+        }
     }
     red[threadIdx.x] = sub < nsub ? acc : 0.0;
     __syncthreads();
@@ -40,7 +52,13 @@ __global__ void k_corr_mean(const double* __restrict__ psum, int64_t n, int d, i
     const int c = threadIdx.x;
     if (c < 2 * d) {
         double t = 0.0;
-        for (int b = 0; b < nblk; ++b) t += psum[(size_t)b * 2 * d + c];
+        for (int b0 = 0; b0 < nblk; b0 += 8) {          // eight partials in flight, summed in block order
+            double p8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p8[e] = b0 + e < nblk ? psum[(size_t)(b0 + e) * 2 * d + c] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (b0 + e < nblk) t += p8[e];
+        }
         mean[c] = t / (double)n;
     }
 }
@@ -55,15 +73,34 @@ __global__ __launch_bounds__(256) void k_corr_moments(const float* __restrict__ 
     double acc[17];
 #pragma unroll
     for (int q = 0; q < 17; ++q) acc[q] = 0.0;
-    for (int64_t r0 = (int64_t)blockIdx.x * CORR_ROWS; r0 < n; r0 += (int64_t)gridDim.x * CORR_ROWS) {
+    // the next chunk's elements are requested (into registers) before the current chunk's products run, so the memory
+    // round trip of a chunk hides under the arithmetic of the one before; CORR_ROWS * 2d / 256 <= 32 elements per thread
+    float nxt[32];
+    auto fetch = [&](int64_t r0) {
         const int nr = (int)((n - r0) < CORR_ROWS ? (n - r0) : CORR_ROWS);
-        for (int idx = threadIdx.x; idx < CORR_ROWS * 2 * d; idx += 256) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int idx = threadIdx.x + e * 256;
             const int r = idx / (2 * d), c = idx - r * 2 * d;
-            double val = 0.0;
-            if (r < nr) val = (c < d ? (double)x[(r0 + r) * d + c] : (double)y[(r0 + r) * d + (c - d)]) - mean[c];
-            tile[r * ld + c] = val;
+            float val = 0.f;
+            if (idx < CORR_ROWS * 2 * d && r < nr) val = c < d ? x[(r0 + r) * d + c] : y[(r0 + r) * d + (c - d)];
+            nxt[e] = val;
+        }
+    };
+    const int64_t step = (int64_t)gridDim.x * CORR_ROWS;
+    if ((int64_t)blockIdx.x * CORR_ROWS < n) fetch((int64_t)blockIdx.x * CORR_ROWS);
+    for (int64_t r0 = (int64_t)blockIdx.x * CORR_ROWS; r0 < n; r0 += step) {
+        const int nr = (int)((n - r0) < CORR_ROWS ? (n - r0) : CORR_ROWS);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int idx = threadIdx.x + e * 256;
+            if (idx < CORR_ROWS * 2 * d) {
+                const int r = idx / (2 * d), c = idx - r * 2 * d;
+                tile[r * ld + c] = r < nr ? (double)nxt[e] - mean[c] : 0.0;
+            }
         }
         __syncthreads();
+        if (r0 + step < n) fetch(r0 + step);
 #pragma unroll
         for (int q = 0; q < 17; ++q) {
             const int o = threadIdx.x + q * 256;
@@ -72,7 +109,9 @@ __global__ __launch_bounds__(256) void k_corr_moments(const float* __restrict__ 
                 if (o < d * d) { ca = o / d; cb = d + (o - ca * d); }
                 else { ca = cb = o - d * d; }
                 double s = 0.0;
-                for (int r = 0; r < nr; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
+                // rows past the chunk's end are zeros in the tile: a fixed trip count lets the loads of several rows be in flight
+#pragma unroll 8
+                for (int r = 0; r < CORR_ROWS; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
                 acc[q] += s;
             }
         }
@@ -91,7 +130,13 @@ __global__ __launch_bounds__(256) void k_corr_final(const double* __restrict__ p
     const int nout = d * d + 2 * d;
     for (int o = threadIdx.x; o < nout; o += 256) {
         double t = 0.0;
-        for (int b = 0; b < nblk; ++b) t += pmom[(size_t)b * nout + o];
+        for (int b0 = 0; b0 < nblk; b0 += 8) {          // eight partials in flight, summed in block order
+            double p8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) p8[e] = b0 + e < nblk ? pmom[(size_t)(b0 + e) * nout + o] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (b0 + e < nblk) t += p8[e];
+        }
         mom[o] = t / (double)(n - 1);        // np.cov normalisation (cancels, kept for rounding parity)
     }
     __syncthreads();

@@ -182,7 +182,9 @@ def runner(args, config, *, replay=None, trace=None, init_seeds=False):
         # the per-step batch scores (runners/ivae.py:86) of all seeds, one launch per epoch
         cc = ops.corr_batched(Se.reshape(nb * K, B, d_latent), Ze.view(nb * K, B, d_latent))
         # the epoch's one sync; summed as the reference does (`train_loss += loss.item()`, runners/ivae.py:84,112: float64,
-        # step by step), which also makes a seed's figure independent of how many seeds are packed beside it
+        # step by step), which also makes a seed's figure independent of how many seeds are packed beside it -- for
+        # packs of fewer than 128 models: from 128 on the in-workgroup pairwise kernel walks with 4 waves per model instead
+        # of 16 / 8 and sums its partials in another grouping (last-bit differences, tests/test_gpu_sweep.py)
         train_loss = losses.cpu().numpy().astype(np.float64).sum(0) / nb
         scores = np.array(_assignment_scores(cc.abs().cpu().numpy()), dtype=np.float64).reshape(nb, K).sum(0) / nb
         for i in range(K):

@@ -121,6 +121,33 @@ def test_every_run_of_a_pack_has_its_own_plateau_scheduler(fused):
     assert any(c is not None for c in first_cut) and len(set(first_cut)) > 1, first_cut
 
 
+def test_pairwise_terms_of_a_model_do_not_depend_on_the_pack_size_beyond_rounding():
+    """The in-workgroup pairwise kernel (batch 64, d <= 12) uses 16 / 8 waves per model in small packs and 4 waves per
+    model from 128 models on: the partial sums meet in another grouping, so a model's loss and gradients agree between a
+    1-model call and a 128-model pack to fp32 rounding (1e-6 of each tensor's max-norm), not to the bit; below 128 models
+    packs are bit-identical to single calls (tests/test_gpu_runner_trace.py::test_packed_seeds_equal_separate_runs)."""
+    from ivae_amd import ops
+    from ivae_amd.trainer import init_packed_params
+    dev = torch.device("cuda:0")
+    shape = ops.ModelShape(5, 5, 40, 100, 3, "xtanh", .1)
+    g = torch.Generator(device=dev).manual_seed(2)
+    p1 = init_packed_params(shape, 1, 3, dev, xavier=False)
+    x = torch.randn(1, 64, 5, generator=g, device=dev)
+    u = torch.zeros(1, 64, 40, device=dev)
+    u[0, torch.arange(64), torch.randint(0, 40, (64,), generator=g, device=dev)] = 1
+    eps = torch.randn(1, 64, 5, generator=g, device=dev)
+    coef = ops.make_coef(100., 1., 0., 10., 40000., .1, True, 64)
+    out = {}
+    for n in (1, 3, 128):
+        rep = lambda t: t.expand(n, *t.shape[1:]).contiguous()
+        loss, z, grads = ops.elbo_fwd_bwd(shape, coef, rep(p1), rep(x), rep(u), rep(eps), ops.Workspace(), n)
+        assert torch.equal(loss, loss[:1].expand(n)) and torch.equal(grads, grads[:1].expand(n, -1))   # same model, same result
+        out[n] = (loss[0].clone(), grads[0].clone())
+    assert torch.equal(out[1][0], out[3][0]) and torch.equal(out[1][1], out[3][1])
+    assert abs(float(out[128][0] - out[1][0])) <= 1e-6 * abs(float(out[1][0]))
+    assert float((out[128][1] - out[1][1]).abs().max()) <= 1e-6 * float(out[1][1].abs().max())
+
+
 def test_two_rank_split_covers_the_grid_once():
     """Rank shares of the run list are disjoint and complete (no GPU work: the partition rule only)."""
     from ivae_amd.dist import model_range

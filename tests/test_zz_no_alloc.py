@@ -39,6 +39,13 @@ def test_corr_static_equals_corr_on_two_calls_second_smaller():
         assert rc == 0, (rc, _lib.lib().ivae_last_hip_error())
         torch.cuda.synchronize()
         assert torch.cuda.memory_allocated(dev) == before
+        # torch's counter only sees torch's allocator: the driver's free-memory figure would show a hipMalloc (or
+        # hipMallocAsync) inside the library.  Compared around a SECOND call (the first one on a device resolves the
+        # scratch symbol and may make the runtime load the code object's data segment).
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        assert _static(x, y, cc) == 0
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free_before
         assert torch.equal(cc, ref), (n, d, float((cc - ref).abs().max()))
         npref = np.corrcoef(x.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64), rowvar=False)[:d, d:]
         assert np.abs(cc.cpu().numpy() - npref).max() < 1e-12
@@ -53,3 +60,28 @@ def test_corr_static_rejects_sizes_beyond_its_scratch():
     assert b"ivae_corr_static" in _lib.lib().ivae_last_hip_error()
     assert float(cc.abs().sum()) == 0.0            # nothing was launched
     assert _static(x[:1, :5].contiguous(), x[:1, :5].contiguous(), cc) == -1     # n < 2: IVAE_E_BADDIMS
+
+
+def test_corr_static_runs_under_graph_capture():
+    """The callers it exists for: under HIP graph capture an allocation fails the capture; ivae_corr_static captures and
+    replays (after one call outside the capture that resolves the scratch symbol), and the replay equals ivae_corr."""
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy(rng.randn(5000, 10).astype(np.float32)).to(dev)
+    y = torch.from_numpy(rng.randn(5000, 10).astype(np.float32)).to(dev) + x
+    cc = torch.zeros(10, 10, dtype=torch.float64, device=dev)
+    assert _static(x, y, cc) == 0
+    torch.cuda.synchronize()
+    cc.zero_()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            rc = _static(x, y, cc)
+    assert rc == 0, (rc, _lib.lib().ivae_last_hip_error())
+    torch.cuda.synchronize()
+    x.mul_(2.0).add_(y)                             # new inputs in the captured buffers
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cc, ops.corr(x, y))
