@@ -478,73 +478,51 @@ __device__ __forceinline__ f32x4 mm_wgrad1(const float* ycol, int sy, const floa
 
 // ---- layer blocks.  Wave w owns rows 16*(w&3).. and the column half 32*(w>>2) + 2c + j of 64-wide outputs.
 
-// Hidden layer(s) forward for NW weight matrices that share the input tile:
-// out_w[b][n] = lrelu(sum_k X[b][k] W_w[n][k]) for n < H, 1 at n == H (bias column of the next layer), 0 beyond.
-// Epilogue of one accumulator row r of a hidden-layer tile pair: activation, constant-1 / zero columns, store,
-// and the value kept for the stash.
-template <class C>
-__device__ __forceinline__ void fwd_epilogue_row(f32x4 (&keep)[2], int r, float* out, float slope, int w, int lane) {
-    const int c = lane & 15, q = lane >> 4;
-    // lanes whose column pair lies past the tile's last one act on that last pair (H, H + 1: the constant-1 and zero
-    // columns) and write the same values there as its owner: no exec-masked store, no branch
-    const int rt = w & 3, col0 = min(32 * (w >> 2) + 2 * c, C::ST - 2);
-    static_assert(C::ST - 2 >= C::H, "the clamped column pair holds no product column");
-    const bool in0 = col0 < C::H, in1 = col0 + 1 < C::H;
-    const float f0 = col0 == C::H ? 1.f : 0.f, f1 = col0 + 1 == C::H ? 1.f : 0.f;
-    const float v0 = in0 ? lrelu(keep[0][r], slope) : f0;
-    const float v1 = in1 ? lrelu(keep[1][r], slope) : f1;
-    keep[0][r] = v0;
-    keep[1][r] = v1;
-    st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
-}
-
-// Product of hidden layer(s) for NW weight matrices that share the input tile: acc_w = X W_w^T (no epilogue).
-template <class C, int NW, int KS, class F>
-__device__ __forceinline__ void fwd_product(const float* X, int sx, const float* const (&W)[NW], int w, int lane,
-                                            f32x4 (&keep)[NW][2], F&& fill) {
-    const int c = lane & 15, q = lane >> 4;
-    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
-    const float* wrow[NW][2];
-#pragma unroll
-    for (int m = 0; m < NW; ++m) {
-        wrow[m][0] = W[m] + mul24(min(col0, C::H - 1), KS);
-        wrow[m][1] = W[m] + mul24(min(col0 + 1, C::H - 1), KS);
-        keep[m][0] = ZERO4;
-        keep[m][1] = ZERO4;
-    }
-    mm_fwd<NW, KS>(X + mul24(16 * rt + c, sx), wrow, q, keep, fill);
-}
-
-// Hidden layer(s) forward for NW weight matrices that share the input tile:
-// out_w[b][n] = lrelu(sum_k X[b][k] W_w[n][k]) for n < H, 1 at n == H (bias column of the next layer), 0 beyond.
-template <class C, int NW, int KS>
-__device__ __forceinline__ void fwd_hidden(const float* X, int sx, const float* const (&W)[NW], float* const (&out)[NW],
-                                           float slope, int w, f32x4 (&keep)[NW][2]) {
-    const int lane = opaque_lane();
-    fwd_product<C, NW, KS>(X, sx, W, w, lane, keep, NoFill());
-#pragma unroll
-    for (int m = 0; m < NW; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(keep[m], r, out[m], slope, w, lane);
-}
-
 // ---- wave-local forward chains.  In the forward stage a wave owns a whole 16-row tile of ONE chain (all 64 output
-// columns = two interleaved tile pairs), so layer l+1 of the chain reads only rows the same wave wrote: no workgroup
-// barrier between the layers of a chain.  keep[p][j] is the pair p = columns 32p + 2c + j.
+// columns = four 16-wide tiles), so layer l+1 of the chain reads only rows the same wave wrote: no workgroup barrier
+// between the layers of a chain.  keep[p][j] is the tile of columns 32p + 16j + c: lane c reads weight row 32p + 16j + c,
+// so the 16 lanes of an operand read walk CONSECUTIVE weight rows (stride KS = 4*odd floats: conflict-free 64-bit reads;
+// interleaved column pairs 2c, 2c + 1 put lanes c and c + 8 on the same banks -- measured: 0.8 us of the 34 us step).
+// The price is 32-bit result stores (columns c and c + 16 are not adjacent): 16 per layer instead of 8.
 template <class C, int KS, class F>
 __device__ __forceinline__ void fwd_rows_product(const float* X, int sx, const float* W, int rt, int lane,
                                                  f32x4 (&keep)[2][2], F&& fill) {
     const int c = lane & 15, q = lane >> 4;
     const float* wrow[2][2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int col0 = 32 * p + 2 * c;
-        wrow[p][0] = W + mul24(min(col0, C::H - 1), KS);
-        wrow[p][1] = W + mul24(min(col0 + 1, C::H - 1), KS);
-        keep[p][0] = ZERO4;
-        keep[p][1] = ZERO4;
-    }
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 32 * p + 16 * j + c;
+            wrow[p][j] = W + mul24(32 * p + 16 * j + 15 < C::H ? col : min(col, C::H - 1), KS);
+            keep[p][j] = ZERO4;
+        }
     mm_fwd<2, KS>(X + mul24(16 * rt + c, sx), wrow, q, keep, fill);
+}
+
+// Epilogue of a wave-local hidden layer: activation, the constant-1 column H (bias column of the next layer) and zeros
+// beyond it, stores, and the values kept for the stash.  Lanes whose column lies past the tile's last one (ST - 1) write
+// that column's value (0) there, as its owner does: no exec-masked store, no branch.
+template <class C>
+__device__ __forceinline__ void fwd_rows_epilogue(f32x4 (&keep)[2][2], float* out, float slope, int rt, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    static_assert(C::ST - 1 > C::H, "the clamped column holds no product column and not the constant 1");
+    float* base = out + mul24(16 * rt + 4 * q, C::ST);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = 32 * p + 16 * j + c;
+            const bool whole = 32 * p + 16 * j + 15 < C::H;            // compile time: every lane's column is a product column
+            float* dst = base + (whole ? col : min(col, C::ST - 1));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = lrelu(keep[p][j][r], slope);
+                if (!whole) v = col < C::H ? v : (col == C::H ? 1.f : 0.f);
+                keep[p][j][r] = v;
+                dst[r * C::ST] = v;
+            }
+        }
 }
 
 // out[b][n] = lrelu(X[b][:] . W[n][:]) for the 16 rows of tile rt, every column; values kept for the stash.
@@ -553,10 +531,7 @@ __device__ __forceinline__ void fwd_rows(const float* X, int sx, const float* W,
                                          f32x4 (&keep)[2][2]) {
     const int lane = opaque_lane();
     fwd_rows_product<C, KS>(X, sx, W, rt, lane, keep, NoFill());
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(keep[p], r, out, slope, rt + 4 * p, lane);
+    fwd_rows_epilogue<C>(keep, out, slope, rt, lane);
 }
 
 // Hand-offs between the two waves that own one row tile (waves rt and rt + 4: the two waves of one SIMD) inside the
@@ -588,21 +563,20 @@ __device__ __forceinline__ void flag_wait(const float* flag, int step_no, float*
     asm volatile("" ::: "memory");
 }
 
-// Write a stashed hidden activation (post-epilogue values kept in registers) back to an LDS tile.
-template <class C>
-__device__ __forceinline__ void restore_tile(const f32x4 (&keep)[2], float* out, int w) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, q = lane >> 4;
-    const int rt = w & 3, col0 = min(32 * (w >> 2) + 2 * c, C::ST - 2);      // clamped like the epilogue that filled `keep`
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, keep[0][r], keep[1][r]);
-}
-
-// Stash of a wave-local layer -> its rows of an LDS tile.
+// Stash of a wave-local layer (post-epilogue values kept in registers, fwd_rows_epilogue's layout) -> its rows of an LDS tile.
 template <class C>
 __device__ __forceinline__ void restore_rows(const f32x4 (&keep)[2][2], float* out, int rt) {
-    restore_tile<C>(keep[0], out, rt);
-    restore_tile<C>(keep[1], out, rt + 4);
+    const int lane = opaque_lane();
+    const int c = lane & 15, q = lane >> 4;
+    float* base = out + mul24(16 * rt + 4 * q, C::ST);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* dst = base + min(32 * p + 16 * j + c, C::ST - 1);       // clamped like the epilogue that filled `keep`
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[r * C::ST] = keep[p][j][r];
+        }
 }
 
 // Head forward (one 16-wide tile per 16 rows; 4 waves): out[b][n] = epi(sum_k X[b][k] W[n][k]), n < N.  EXP: exp().
@@ -635,25 +609,6 @@ __device__ __forceinline__ void dgrad_hidden(const float* dY, int sy, const floa
             const float v1 = in1 ? acc[1][r] * (h.y > 0.f ? 1.f : slope) : 0.f;
             st2(out + row + col0, v0, v1);
         }
-    }
-}
-
-// Same with the activation mask taken from the wave's stash registers (same (row, column) mapping as the
-// epilogue of fwd_hidden): no LDS read, and the activation tile need not be restored for it.
-template <class C, int NS, int N, int KS, int KB>
-__device__ __forceinline__ void dgrad_hidden_reg(const float* dY, int sy, const float* W, const f32x4 (&keep)[2], float* out,
-                                                 float slope, int w) {
-    const int lane = opaque_lane();
-    const int c = lane & 15, q = lane >> 4;
-    const int rt = w & 3, col0 = 32 * (w >> 2) + 2 * c;
-    f32x4 acc[2] = {ZERO4, ZERO4};
-    mm_dgrad<NS, N, KS>(dY + mul24(16 * rt + c, sy), W + min(col0, KS - 2), q, acc);
-    const bool in0 = col0 < KB, in1 = col0 + 1 < KB;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float v0 = in0 ? acc[0][r] * (keep[0][r] > 0.f ? 1.f : slope) : 0.f;
-        const float v1 = in1 ? acc[1][r] * (keep[1][r] > 0.f ? 1.f : slope) : 0.f;
-        if (col0 < C::ST) st2(out + mul24(16 * rt + 4 * q, C::ST) + r * C::ST + col0, v0, v1);
     }
 }
 
@@ -1027,7 +982,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                 const int ln = opaque_lane();
                 fwd_rows_product<C, KS_H>(T0, ST, arena + C::off_of(L_G1), rt, ln, s2, NoFill());
                 STAMPW(9);
-                for (int p = 0; p < 2; ++p) for (int r = 0; r < 4; ++r) fwd_epilogue_row<C>(s2[p], r, T2, slope, rt + 4 * p, ln);
+                fwd_rows_epilogue<C>(s2, T2, slope, rt, ln);
             }
 #else
             fwd_rows<C, KS_H>(T0, ST, arena + C::off_of(L_G1), T2, slope, rt, s2);
@@ -1094,15 +1049,13 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             if constexpr (C::HAS_U) {          // take over the partner's h1l (same register layout as a stash)
                 flag_wait(flagL + rt * ST, step_no, flagE);
                 const int ln = opaque_lane();
+                const float* base = T1 + mul24(16 * rt + 4 * (ln >> 4), ST);
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col0 = 32 * p + 2 * (ln & 15);
-                        const f32x2 h = ld2(T1 + mul24(16 * rt + 4 * (ln >> 4), ST) + r * ST + min(col0, ST - 2));
-                        s3[p][0][r] = h.x;
-                        s3[p][1][r] = h.y;
-                    }
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s3[p][j][r] = base[r * ST + min(32 * p + 16 * j + (ln & 15), ST - 1)];
             }
         } else {
             STAMPW(0);
