@@ -344,6 +344,13 @@ __device__ __forceinline__ f32x4 mm_dgrad1(const float* yrow, const float* wcol,
 // acc[j] += dY[b][n] * X[b][col0 + j], b in [0, 64).  ycol = dY + n, xcol = X + col0.  WG_G groups of 2 batch
 // k-steps (4 MFMAs each); fill(t) is independent vector work issued between the MFMAs of group t.
 #define WG_G (FT_B / 8)
+// Which batch rows a weight-gradient MFMA contracts: k-slot q of the k-step (t, i) takes row 16*(t/2) + 2*(t%2) + i +
+// {0, 8, 4, 12}[q] (any assignment is a valid contraction as long as both operands use it).  With row strides of 52
+// floats (= 52 mod 64 banks) the four k-slots then sit 0, 32, 16, 48 banks apart: the 32-bit reads of the delta operand
+// (16 consecutive floats per slot) and the 64-bit reads of the activation operand (32 consecutive floats per slot, two
+// slots per LDS cycle) are conflict-free, which consecutive rows q = 0..3 (52 banks apart) are not.
+__device__ __forceinline__ constexpr int wg_row(int t, int i) { return 16 * (t / 2) + 2 * (t % 2) + i; }
+__device__ __forceinline__ int wg_qoff(int q) { return ((q & 1) << 3) | ((q >> 1) << 2); }
 template <class F>
 __device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float* xcol, int sx, int q, f32x4 (&acc)[2], F&& fill) {
     constexpr int PF = 2, R = PF + 1;
@@ -353,8 +360,8 @@ __device__ __forceinline__ void mm_wgrad(const float* ycol, int sy, const float*
         if (t < WG_G) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[t % R][i] = ycol[(8 * t + 4 * i + q) * sy];
-                b[t % R][i] = ld2(xcol + (8 * t + 4 * i + q) * sx);
+                a[t % R][i] = ycol[(wg_row(t, i) + wg_qoff(q)) * sy];
+                b[t % R][i] = ld2(xcol + (wg_row(t, i) + wg_qoff(q)) * sx);
             }
         }
     };
@@ -420,8 +427,8 @@ __device__ __forceinline__ void mm_dgrad_wgrad(const float* yrow, const float* w
 #elif defined(IVAE_DIAG) && defined(FT_EXP_NOLOAD)
                 asm volatile("" : "=v"(wa[t % WR][i]), "=v"(wb[t % WR][i]));
 #else
-                wa[t % WR][i] = ycol[(8 * t + 4 * i + q) * sy];
-                wb[t % WR][i] = ld2(xcol + (8 * t + 4 * i + q) * sx);
+                wa[t % WR][i] = ycol[(wg_row(t, i) + wg_qoff(q)) * sy];
+                wb[t % WR][i] = ld2(xcol + (wg_row(t, i) + wg_qoff(q)) * sx);
 #endif
             }
         }
@@ -468,7 +475,7 @@ __device__ __forceinline__ void mm_dgrad_wgrad(const float* yrow, const float* w
 __device__ __forceinline__ f32x4 mm_wgrad1(const float* ycol, int sy, const float* xcol, int sx, int q) {
     float a[FT_B / 4], b[FT_B / 4];
 #pragma unroll
-    for (int t = 0; t < FT_B / 4; ++t) { a[t] = ycol[(4 * t + q) * sy]; b[t] = xcol[(4 * t + q) * sx]; }
+    for (int t = 0; t < FT_B / 4; ++t) { a[t] = ycol[(16 * (t / 4) + t % 4 + wg_qoff(q)) * sy]; b[t] = xcol[(16 * (t / 4) + t % 4 + wg_qoff(q)) * sx]; }
     SCHED_FENCE();
     f32x4 e = ZERO4, o = ZERO4;
 #pragma unroll
