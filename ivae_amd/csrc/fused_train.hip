@@ -541,6 +541,134 @@ __device__ __forceinline__ void fwd_rows(const float* X, int sx, const float* W,
     fwd_rows_epilogue<C>(keep, out, slope, rt, lane);
 }
 
+// ---- the same chains as continuous MFMA streams (round 3).  A layer's product runs as two passes, tile pair p = 0
+// (columns 0..31) then p = 1 (columns 32..63), and no epilogue ever runs with the matrix pipe idle: the epilogue of pair 0 is
+// issued between the MFMAs of pair 1, and the epilogue of pair 1 is left PENDING -- the next layer of the chain performs it
+// between the MFMAs of its own first pass, whose first four k-groups (k < 32) only read columns the pair-0 epilogue wrote.
+// The operand ring of a pass is requested inside the pass before it, so a pass starts on operands that are already there.
+template <int KS>
+struct PairOps {
+    static constexpr int G = (KS - 4) / 8, R = 3;
+    static_assert(KS == 8 * G + 4 && G >= 1, "row strides are 4*odd, >= 12");
+    const float* xrow;
+    const float* w0;
+    const float* w1;
+    f32x2 a[R], b0[R], b1[R];
+    float at, bt0, bt1;
+    __device__ __forceinline__ void fetch(int t, int q) {
+        if (t < G) {
+            a[t % R] = ld2(xrow + 8 * t + 2 * q);
+            b0[t % R] = ld2(w0 + 8 * t + 2 * q);
+            b1[t % R] = ld2(w1 + 8 * t + 2 * q);
+        } else if (t == G) {
+            at = xrow[8 * G + q];
+            bt0 = w0[8 * G + q];
+            bt1 = w1[8 * G + q];
+        }
+    }
+};
+
+// operands of pair p of the layer X -> W for row tile rt; the first two k-groups are requested right away
+template <class C, int KS>
+__device__ __forceinline__ void pair_ops_start(PairOps<KS>& o, const float* X, int sx, const float* W, int rt, int lane, int p) {
+    const int c = lane & 15, q = lane >> 4;
+    o.xrow = X + mul24(16 * rt + c, sx);
+    o.w0 = W + mul24(min(32 * p + c, C::H - 1), KS);
+    o.w1 = W + mul24(min(32 * p + 16 + c, C::H - 1), KS);
+    o.fetch(0, q);
+    o.fetch(1, q);
+}
+
+// one pass: acc[j] += X W_j^T over the whole contraction; fill(t) is issued between the MFMAs of k-group t
+template <int KS, class F>
+__device__ __forceinline__ void pair_pass(PairOps<KS>& o, int q, f32x4 (&acc)[2], F&& fill) {
+    constexpr int G = PairOps<KS>::G, R = PairOps<KS>::R;
+#pragma unroll
+    for (int t = 0; t < G; ++t) {
+        const int cur = t % R;
+        o.fetch(t + 2, q);
+        SCHED_FENCE();
+        acc[0] = mfma4(o.a[cur].x, o.b0[cur].x, acc[0]);
+        acc[1] = mfma4(o.a[cur].x, o.b1[cur].x, acc[1]);
+        acc[0] = mfma4(o.a[cur].y, o.b0[cur].y, acc[0]);
+        acc[1] = mfma4(o.a[cur].y, o.b1[cur].y, acc[1]);
+        fill(t);
+        interleave_mfma<4, 7, 2>();
+        SCHED_FENCE();
+    }
+    acc[0] = mfma4(o.at, o.bt0, acc[0]);
+    acc[1] = mfma4(o.at, o.bt1, acc[1]);
+}
+
+// epilogue of tile (p, j) = columns 32p + 16j + c of a hidden layer, rows 16rt + 4q + r: activation, constant-1 column H,
+// zeros beyond, 32-bit stores; lanes past the tile's last column write that column's value (0) there, as its owner does
+template <class C>
+__device__ __forceinline__ void tile_epilogue(f32x4& v, int p, int j, float* out, float slope, int rt, int lane) {
+    const int c = lane & 15, q = lane >> 4;
+    const int col = 32 * p + 16 * j + c;
+    const bool whole = 32 * p + 16 * j + 15 < C::H;                // every lane's column is a product column (p, j: constants)
+    float* dst = out + mul24(16 * rt + 4 * q, C::ST) + (whole ? col : min(col, C::ST - 1));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float x = lrelu(v[r], slope);
+        if (!whole) x = col < C::H ? x : (col == C::H ? 1.f : 0.f);
+        v[r] = x;
+        dst[r * C::ST] = x;
+    }
+}
+
+// One hidden layer of a chain.  o0: operands of pair 0, already started.  keep: this layer's four tiles -- on return
+// keep[0][*] hold the epilogued pair 0 (stored to `out`), keep[1][*] the RAW accumulators of pair 1 (pending).  PEND: the
+// previous layer's pending pair (`pend`, epilogued here into `pend_out` = this layer's input tile).  next(): called late in
+// the second pass, for the caller to start the operands of whatever follows.
+template <class C, int KS, bool PEND, class NEXT>
+__device__ __forceinline__ void chain_layer(PairOps<KS>& o0, const float* X, int sx, const float* W, float* out, float slope,
+                                            int rt, int lane, f32x4 (&keep)[2][2], f32x4 (&pend)[2], float* pend_out,
+                                            NEXT&& next) {
+    constexpr int G = PairOps<KS>::G;
+    const int q = lane >> 4;
+    PairOps<KS> o1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { keep[p][0] = ZERO4; keep[p][1] = ZERO4; }
+    pair_pass<KS>(o0, q, keep[0], [&](int t) __attribute__((always_inline)) {
+        if (PEND && t < 2) tile_epilogue<C>(pend[t], 1, t, pend_out, slope, rt, lane);       // before k-group 4 is requested
+        if (t == (G >= 2 ? G - 2 : 0)) pair_ops_start<C, KS>(o1, X, sx, W, rt, lane, 1);
+    });
+    pair_pass<KS>(o1, q, keep[1], [&](int t) __attribute__((always_inline)) {
+        if (t < 2) tile_epilogue<C>(keep[0][t], 0, t, out, slope, rt, lane);
+        if (G == 1 && t == 0) tile_epilogue<C>(keep[0][1], 0, 1, out, slope, rt, lane);
+        if (t == (G >= 2 ? G - 2 : 0)) next();
+    });
+}
+
+// Head of a chain (one 16-wide tile, contraction over the H + 1 columns of the last hidden tile X) with that layer's
+// pending pair: the k < 32 part first, the pending epilogue between its MFMAs, then the rest.
+template <class C>
+__device__ __forceinline__ f32x4 chain_head(const float* xrow, const float* wrow, int q, f32x4 (&pend)[2], float* pend_out,
+                                            float slope, int rt, int lane) {
+    constexpr int KS = C::KS_H, G = (KS - 4) / 8;
+    static_assert(G >= 5, "the head's contraction covers k < 32 in its first four k-groups");
+    f32x2 a[G], b[G];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { a[t] = ld2(xrow + 8 * t + 2 * q); b[t] = ld2(wrow + 8 * t + 2 * q); }
+    SCHED_FENCE();
+    f32x4 e = ZERO4, o = ZERO4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { e = mfma4(a[t].x, b[t].x, e); o = mfma4(a[t].y, b[t].y, o); }
+    tile_epilogue<C>(pend[0], 1, 0, pend_out, slope, rt, lane);
+    tile_epilogue<C>(pend[1], 1, 1, pend_out, slope, rt, lane);
+    interleave_mfma<8, 6, 2>();
+    SCHED_FENCE();
+#pragma unroll
+    for (int t = 4; t < G; ++t) { a[t] = ld2(xrow + 8 * t + 2 * q); b[t] = ld2(wrow + 8 * t + 2 * q); }
+    const float at = xrow[8 * G + q], bt = wrow[8 * G + q];
+    SCHED_FENCE();
+#pragma unroll
+    for (int t = 4; t < G; ++t) { e = mfma4(a[t].x, b[t].x, e); o = mfma4(a[t].y, b[t].y, o); }
+    e = mfma4(at, bt, e);
+    return e + o;
+}
+
 // Hand-offs between the two waves that own one row tile (waves rt and rt + 4: the two waves of one SIMD) inside the
 // forward stage.  A flag is one LDS word holding the number of the step it was last raised in; it lives in the unused
 // pad column of the resident input tile (column KIN + 1 of T3, which multiplies zero weight columns only).  The
@@ -560,6 +688,9 @@ __device__ __forceinline__ void flag_raise(float* flag, int step_no) {
 // the model's error word; from that step on every loss the model reports is NaN (k_train_steps, loss out), so a missed
 // hand-off can never pass as a trained model.
 __device__ __forceinline__ void flag_wait(const float* flag, int step_no, float* err) {
+#if defined(IVAE_DIAG) && defined(FT_EXP_NOFLAGWAIT)     // timing experiment (wrong results)
+    return;
+#endif
     bool seen = false;
 #pragma unroll 1
     for (int spin = 0; spin < (1 << 16); ++spin) {
@@ -980,23 +1111,32 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
         float lsum = 0.f;
         const int step_no = s + 1;
         load_xu<C>(xu, next_row, xd, ud);                  // next batch's rows start to arrive in registers
+#if defined(IVAE_DIAG) && defined(FT_EXP_FWD_ONLY_G)      // timing experiment (wrong results): waves 4-7 idle in the forward stage
+        if (w >= 4) {} else
+#elif defined(IVAE_DIAG) && defined(FT_EXP_FWD_ONLY_V)    // ... waves 0-3 idle
+        if (w < 4) {} else
+#endif
         if (w < 4) {
             STAMPW(0);
-            fwd_rows<C, KS_E0>(T3, ST, arena + C::off_of(L_G0), T0, slope, rt, s1);
-            STAMPW(1);
-#ifdef FT_PROF
+            f32x4 none[2];                   // (no pending pair in front of a chain's first layer)
             {
-                const int ln = opaque_lane();
-                fwd_rows_product<C, KS_H>(T0, ST, arena + C::off_of(L_G1), rt, ln, s2, NoFill());
-                STAMPW(9);
-                fwd_rows_epilogue<C>(s2, T2, slope, rt, ln);
+                PairOps<KS_E0> oG0;
+                PairOps<KS_H> oG1;
+                pair_ops_start<C, KS_E0>(oG0, T3, ST, arena + C::off_of(L_G0), rt, lane, 0);
+                chain_layer<C, KS_E0, false>(oG0, T3, ST, arena + C::off_of(L_G0), T0, slope, rt, lane, s1, none, nullptr,
+                                             LAMBDA { pair_ops_start<C, KS_H>(oG1, T0, ST, arena + C::off_of(L_G1), rt, lane, 0); });
+                STAMPW(1);
+                chain_layer<C, KS_H, true>(oG1, T0, ST, arena + C::off_of(L_G1), T2, slope, rt, lane, s2, s1[1], T0, LAMBDA {});
             }
-#else
-            fwd_rows<C, KS_H>(T0, ST, arena + C::off_of(L_G1), T2, slope, rt, s2);
-#endif
             STAMPW(2);
             if constexpr (C::HAS_U) flag_raise(flagG + rt * ST, step_no);          // T0's rows rt may be overwritten (h2l)
-            fwd_head<C, DL, false>(T2, arena + C::off_of(L_G2), sG, rt);
+            {
+                const f32x4 acc = chain_head<C>(T2 + mul24(16 * rt + c, ST), arena + C::off_of(L_G2) + mul24(min(c, DL - 1), KS_H), q,
+                                                s2[1], T2, slope, rt, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c < DL) sG[mul24(16 * rt + 4 * q, SS) + r * SS + c] = acc[r];
+            }
             STAMPW(3);
             flag_wait(flagV + rt * ST, step_no, flagE);
             STAMPW(4);
@@ -1031,15 +1171,21 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             }
             flag_raise(flagZ + rt * ST, step_no);
             STAMPW(5);
+            f32x4 kF1[2][2];
             {
-                f32x4 keep[2][2];
-                fwd_rows<C, KS_F0>(sZ, SS, arena + C::off_of(L_F0), T2, slope, rt, keep);      // h1f
+                f32x4 kF0[2][2];
+                PairOps<KS_F0> oF0;
+                PairOps<KS_H> oF1;
+                pair_ops_start<C, KS_F0>(oF0, sZ, SS, arena + C::off_of(L_F0), rt, lane, 0);
+                chain_layer<C, KS_F0, false>(oF0, sZ, SS, arena + C::off_of(L_F0), T2, slope, rt, lane, kF0, none, nullptr,       // h1f
+                                             LAMBDA { pair_ops_start<C, KS_H>(oF1, T2, ST, arena + C::off_of(L_F1), rt, lane, 0); });
                 STAMPW(6);
-                fwd_rows<C, KS_H>(T2, ST, arena + C::off_of(L_F1), T4, slope, rt, keep);       // h2f
+                chain_layer<C, KS_H, true>(oF1, T2, ST, arena + C::off_of(L_F1), T4, slope, rt, lane, kF1, kF0[1], T2, LAMBDA {});  // h2f
                 STAMPW(7);
             }
-            // decoder head f, log p(x|z) and dLoss/df -> sO
-            const f32x4 acc = mm_fwd1<KS_H>(T4 + (16 * rt + c) * ST, arena + C::off_of(L_F2) + min(c, DD - 1) * KS_H, q);
+            // decoder head f (with h2f's pending columns), log p(x|z) and dLoss/df -> sO
+            const f32x4 acc = chain_head<C>(T4 + mul24(16 * rt + c, ST), arena + C::off_of(L_F2) + mul24(min(c, DD - 1), KS_H), q,
+                                            kF1[1], T4, slope, rt, lane);
             const float inv_dv = 1.f / A.decoder_var, logdv = logf(A.decoder_var);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1066,24 +1212,43 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             }
         } else {
             STAMPW(0);
-            fwd_rows<C, KS_E0>(T3, ST, arena + C::off_of(L_V0), T1, slope, rt, s1);
-            STAMPW(1);
-            fwd_rows<C, KS_H>(T1, ST, arena + C::off_of(L_V1), T4, slope, rt, s2);
+            f32x4 none[2];
+            {
+                PairOps<KS_E0> oV0;
+                PairOps<KS_H> oV1;
+                pair_ops_start<C, KS_E0>(oV0, T3, ST, arena + C::off_of(L_V0), rt, lane, 0);
+                chain_layer<C, KS_E0, false>(oV0, T3, ST, arena + C::off_of(L_V0), T1, slope, rt, lane, s1, none, nullptr,
+                                             LAMBDA { pair_ops_start<C, KS_H>(oV1, T1, ST, arena + C::off_of(L_V1), rt, lane, 0); });
+                STAMPW(1);
+                chain_layer<C, KS_H, true>(oV1, T1, ST, arena + C::off_of(L_V1), T4, slope, rt, lane, s2, s1[1], T1, LAMBDA {});
+            }
             STAMPW(2);
-            fwd_head<C, DL, true>(T4, arena + C::off_of(L_V2), sV, rt);
+            {
+                const f32x4 acc = chain_head<C>(T4 + mul24(16 * rt + c, ST), arena + C::off_of(L_V2) + mul24(min(c, DL - 1), KS_H), q,
+                                                s2[1], T4, slope, rt, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c < DL) sV[mul24(16 * rt + 4 * q, SS) + r * SS + c] = fexp(acc[r]);
+            }
             if (!(A.fault & 1)) flag_raise(flagV + rt * ST, step_no);      // (fault injection: tests/test_gpu_fused.py)
             STAMPW(3);
             if constexpr (C::HAS_U) {
-                {
-                    f32x4 keep[2][2];
-                    fwd_rows<C, KS_L0>(T3 + C::UOFF, ST, arena + C::off_of(L_L0), T1, slope, rt, keep);
-                }
-                flag_raise(flagL + rt * ST, step_no);
+                f32x4 kL0[2][2];
+                PairOps<KS_L0> oL0;
+                PairOps<KS_H> oL1;
+                pair_ops_start<C, KS_L0>(oL0, T3 + C::UOFF, ST, arena + C::off_of(L_L0), rt, lane, 0);
+                chain_layer<C, KS_L0, false>(oL0, T3 + C::UOFF, ST, arena + C::off_of(L_L0), T1, slope, rt, lane, kL0, none, nullptr,
+                                             LAMBDA { pair_ops_start<C, KS_H>(oL1, T1, ST, arena + C::off_of(L_L1), rt, lane, 0); });
                 STAMPW(4);
-                flag_wait(flagG + rt * ST, step_no, flagE);
-                fwd_rows<C, KS_H>(T1, ST, arena + C::off_of(L_L1), T0, slope, rt, s3);
+                flag_wait(flagG + rt * ST, step_no, flagE);                  // T0's rows rt are free (the g chain has read h1g)
+                chain_layer<C, KS_H, true>(oL1, T1, ST, arena + C::off_of(L_L1), T0, slope, rt, lane, s3, kL0[1], T1, LAMBDA {});
+                flag_raise(flagL + rt * ST, step_no);                        // h1l (with its pending columns) is in T1
                 STAMPW(5);
-                fwd_head<C, DL, true>(T0, arena + C::off_of(L_L2), sL, rt);
+                const f32x4 acc = chain_head<C>(T0 + mul24(16 * rt + c, ST), arena + C::off_of(L_L2) + mul24(min(c, DL - 1), KS_H), q,
+                                                s3[1], T0, slope, rt, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (c < DL) sL[mul24(16 * rt + 4 * q, SS) + r * SS + c] = fexp(acc[r]);
                 STAMPW(6);
             }
             flag_wait(flagZ + rt * ST, step_no, flagE);
