@@ -1212,6 +1212,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
             }
         } else {
             STAMPW(0);
+            // The variance chain is what the partner's reparameterisation waits for, and with two 2-accumulator MFMA streams
+            // on one SIMD the older wave (the g chain) would take the pipe until its stream ends: priority for this chain.
+            __builtin_amdgcn_s_setprio(1);
             f32x4 none[2];
             {
                 PairOps<KS_E0> oV0;
@@ -1231,6 +1234,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_train_steps(FusedArgs A) {
                     if (c < DL) sV[mul24(16 * rt + 4 * q, SS) + r * SS + c] = fexp(acc[r]);
             }
             if (!(A.fault & 1)) flag_raise(flagV + rt * ST, step_no);      // (fault injection: tests/test_gpu_fused.py)
+            __builtin_amdgcn_s_setprio(0);
             STAMPW(3);
             if constexpr (C::HAS_U) {
                 f32x4 kL0[2][2];
