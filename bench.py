@@ -348,8 +348,10 @@ def main():
         # a scratch copy of the state first (not counted, state restored), then the W warmup steps, then time K steps.
         saved = [t.clone() for t in (tr.params, tr.exp_avg, tr.exp_avg_sq)]
         t_keep, t0 = tr.t, time.perf_counter()
+        # whole launches only: a profiler's per-kernel mean over the process then averages launches of one length
+        chunk = tr.CHUNK if fused else 125
         while time.perf_counter() - t0 < args.spinup_ms * 1e-3:
-            advance(125, False)
+            advance(chunk * max(1, 125 // chunk), False)
             torch.cuda.synchronize()
         for dst, src in zip((tr.params, tr.exp_avg, tr.exp_avg_sq), saved):
             dst.copy_(src)

@@ -76,6 +76,18 @@ size_t pairwise_ws_floats(int n_rows, int n_cols, int d) {
 #define LN2 0.6931471805599453f
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Round 3: the walks are bound by vector-instruction issue (tools/ubench/valu_pk_rate.hip: a packed fp32 instruction costs
+// what a plain one costs and does two elements), so the arithmetic runs on PAIRS of adjacent latent dimensions k, k+1 --
+// operands of a pair are adjacent registers / adjacent LDS words already -- as v_pk_add / v_pk_mul / v_pk_fma_f32.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fexp2(f2 x) { return f2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
+__device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
+// A log-sum-exp needs a reference that is not below the largest term.  The exact maximum costs a whole extra pass over
+// the columns; T2 <= A2 (the quadratic term only lowers it), so the largest A2 of the columns walked -- known without
+// looking at the row -- is a valid reference.  It can be far above the true maximum only for a row that is far from every
+// column, and then the sum underflows: a sum below PAIR_TINY sends the wave through the exact two-pass walk instead.
+#define PAIR_TINY 1e-30f
+
 // Column constants of slice [j0, j0+nj) -> LDS, three (nj, DP) arrays.
 template <int DP>
 __device__ __forceinline__ void stage_cols(const float* __restrict__ g, const float* __restrict__ v, int j0, int nj, int d,
@@ -93,24 +105,40 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ g, const fl
     }
 }
 
-// Per-slice statistics: max and sum-of-exp2 over the slice's columns, for every k and for the sum over k.
+// Reference values of a staged slice: U[k] = max_j A2[j][k] (k < DP), U[DP] = max_j sum_k A2[j][k].  AS: (nj) scratch,
+// part: (4, 64) scratch, all in LDS; ends with a barrier.  PB = 256 threads.
 template <int DP>
-__global__ __launch_bounds__(PB) void k_pair_stats(PairGeom P, const float* __restrict__ z, const float* __restrict__ g,
-                                                   const float* __restrict__ v, float* __restrict__ ws, int gx) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int bx = blockIdx.x % gx;
-    const size_t mo = (size_t)(blockIdx.x / gx) * P.mstride;
-    z += mo; g += mo; v += mo; ws += mo;
-    const int d = P.d, sl = blockIdx.y, j0 = sl * P.CS, nj = min(P.CS, P.n_cols - j0);
-    float* G = sm; float* W2 = G + P.CS * DP; float* A2 = W2 + P.CS * DP;
-    stage_cols<DP>(g, v, j0, nj, d, G, W2, A2);
-    __syncthreads();
-    const int i = bx * PB + threadIdx.x;
-    const int ic = min(i, P.n_rows - 1);
-    float zi[DP], m[DP], s[DP];
+__device__ __forceinline__ void slice_refs(const float* A2, int nj, float* AS, float* part, float* U) {
+    static_assert(DP <= 63, "one lane per latent dimension and one for the sum");
+    for (int j = threadIdx.x; j < nj; j += PB) {
+        float a = 0.f;
 #pragma unroll
-    for (int k = 0; k < DP; ++k) { zi[k] = k < d ? z[(size_t)ic * d + k] : 0.f; m[k] = NEG_BIG; s[k] = 0.f; }
-    float mS = NEG_BIG, sS = 0.f;
+        for (int k = 0; k < DP; ++k) a += A2[j * DP + k];
+        AS[j] = a;
+    }
+    __syncthreads();
+    const int k = threadIdx.x & 63, pt = threadIdx.x >> 6;
+    float mx = NEG_BIG;
+    if (k <= DP)
+        for (int j = pt; j < nj; j += PB / 64) mx = fmaxf(mx, k < DP ? A2[j * DP + k] : AS[j]);
+    part[pt * 64 + k] = mx;
+    __syncthreads();
+    if (threadIdx.x <= DP) {
+        float m = part[threadIdx.x];
+#pragma unroll
+        for (int p = 1; p < PB / 64; ++p) m = fmaxf(m, part[p * 64 + threadIdx.x]);
+        U[threadIdx.x] = m;
+    }
+    __syncthreads();
+}
+
+// Exact two-pass statistics of one row over staged columns [0, nj): the fallback of the walks below.
+template <int DP>
+__device__ __noinline__ void row_stats_exact(const float* zi, const float* G, const float* W2, const float* A2, int nj,
+                                             float* m, float* s, float& mS, float& sS) {
+#pragma unroll
+    for (int k = 0; k < DP; ++k) { m[k] = NEG_BIG; s[k] = 0.f; }
+    mS = NEG_BIG; sS = 0.f;
     for (int j = 0; j < nj; ++j) {
         float S = 0.f;
 #pragma unroll
@@ -133,6 +161,61 @@ __global__ __launch_bounds__(PB) void k_pair_stats(PairGeom P, const float* __re
         }
         sS += fexp2(S - mS);
     }
+}
+
+// One pass: sums of exp2(T2 - reference) with the references m[k], mS given (slice_refs); packed over k pairs.
+template <int DP>
+__device__ __forceinline__ void row_stats_fast(const float* zi, const float* G, const float* W2, const float* A2, int j0, int j1,
+                                               const float* m, float* s, float mS, float& sS) {
+    static_assert(DP % 2 == 0, "pairs of latent dimensions");
+    f2 z2[DP / 2], m2[DP / 2], s2[DP / 2];
+#pragma unroll
+    for (int h = 0; h < DP / 2; ++h) { z2[h] = f2{zi[2 * h], zi[2 * h + 1]}; m2[h] = f2{m[2 * h], m[2 * h + 1]}; s2[h] = splat(0.f); }
+    float acc = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        const f2* Gj = reinterpret_cast<const f2*>(G + j * DP);
+        const f2* Wj = reinterpret_cast<const f2*>(W2 + j * DP);
+        const f2* Aj = reinterpret_cast<const f2*>(A2 + j * DP);
+        f2 S2 = splat(0.f);
+#pragma unroll
+        for (int h = 0; h < DP / 2; ++h) {
+            const f2 dq = z2[h] - Gj[h];
+            const f2 t = Aj[h] - dq * dq * Wj[h];
+            s2[h] += fexp2(t - m2[h]);
+            S2 += t;
+        }
+        acc += fexp2(S2.x + S2.y - mS);
+    }
+#pragma unroll
+    for (int h = 0; h < DP / 2; ++h) { s[2 * h] = s2[h].x; s[2 * h + 1] = s2[h].y; }
+    sS = acc;
+}
+
+// Per-slice statistics: max and sum-of-exp2 over the slice's columns, for every k and for the sum over k.
+template <int DP>
+__global__ __launch_bounds__(PB) void k_pair_stats(PairGeom P, const float* __restrict__ z, const float* __restrict__ g,
+                                                   const float* __restrict__ v, float* __restrict__ ws, int gx) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int bx = blockIdx.x % gx;
+    const size_t mo = (size_t)(blockIdx.x / gx) * P.mstride;
+    z += mo; g += mo; v += mo; ws += mo;
+    const int d = P.d, sl = blockIdx.y, j0 = sl * P.CS, nj = min(P.CS, P.n_cols - j0);
+    float* G = sm; float* W2 = G + P.CS * DP; float* A2 = W2 + P.CS * DP;
+    float* AS = A2 + P.CS * DP; float* part = AS + P.CS; float* U = part + PB;
+    stage_cols<DP>(g, v, j0, nj, d, G, W2, A2);
+    __syncthreads();
+    slice_refs<DP>(A2, nj, AS, part, U);
+    const int i = bx * PB + threadIdx.x;
+    const int ic = min(i, P.n_rows - 1);
+    float zi[DP], m[DP], s[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) { zi[k] = k < d ? z[(size_t)ic * d + k] : 0.f; m[k] = U[k]; }
+    float mS = U[DP], sS;
+    row_stats_fast<DP>(zi, G, W2, A2, 0, nj, m, s, mS, sS);
+    bool tiny = sS < PAIR_TINY;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) tiny |= s[k] < PAIR_TINY;
+    if (__any(tiny)) row_stats_exact<DP>(zi, G, W2, A2, nj, m, s, mS, sS);       // (wave-uniform branch)
     if (i < P.n_rows) {
         float* pm = ws + P.o_pm + (size_t)sl * (d + 1) * P.n_rows + i;
         float* ps = ws + P.o_ps + (size_t)sl * (d + 1) * P.n_rows + i;
@@ -203,33 +286,38 @@ __global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const
         __syncthreads();
         const int i = bx * PB + threadIdx.x;
         const int ic = min(i, P.n_rows - 1);
-        float zi[DP], lk[DP], acc[DP];
+        f2 zi[DP / 2], lk[DP / 2], acc[DP / 2];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) {
-            zi[k] = k < d ? z[(size_t)ic * d + k] : 0.f;
-            lk[k] = k < d ? lse_k[(size_t)ic * d + k] * LOG2E : 0.f;
-            acc[k] = 0.f;
+        for (int h = 0; h < DP / 2; ++h) {
+            const int k = 2 * h;
+            zi[h] = f2{k < d ? z[(size_t)ic * d + k] : 0.f, k + 1 < d ? z[(size_t)ic * d + k + 1] : 0.f};
+            lk[h] = f2{k < d ? lse_k[(size_t)ic * d + k] * LOG2E : 0.f, k + 1 < d ? lse_k[(size_t)ic * d + k + 1] * LOG2E : 0.f};
+            acc[h] = splat(0.f);
         }
         const float LS = lse_s[ic] * LOG2E;
+        const f2 cQ2 = splat(cQ);
         for (int j = 0; j < nj; ++j) {
-            float tt[DP], rr[DP];
-            float S = 0.f;
+            const f2* Gj = reinterpret_cast<const f2*>(G + j * DP);
+            const f2* Wj = reinterpret_cast<const f2*>(W2 + j * DP);
+            const f2* Aj = reinterpret_cast<const f2*>(A2 + j * DP);
+            f2 tt[DP / 2], rr[DP / 2];
+            f2 S2 = splat(0.f);
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float dq = zi[k] - G[j * DP + k];
-                rr[k] = dq * W2[j * DP + k];                       // (z - g) / v * log2(e) / 2
-                tt[k] = A2[j * DP + k] - dq * rr[k];
-                S += tt[k];
+            for (int h = 0; h < DP / 2; ++h) {
+                const f2 dq = zi[h] - Gj[h];
+                rr[h] = dq * Wj[h];                                // (z - g) / v * log2(e) / 2
+                tt[h] = Aj[h] - dq * rr[h];
+                S2 += tt[h];
             }
-            const float Pij = cP * fexp2(S - LS);
+            const f2 Pij = splat(cP * fexp2(S2.x + S2.y - LS));
 #pragma unroll
-            for (int k = 0; k < DP; ++k) acc[k] -= (Pij + cQ * fexp2(tt[k] - lk[k])) * rr[k];
+            for (int h = 0; h < DP / 2; ++h) acc[h] -= (Pij + cQ2 * fexp2(tt[h] - lk[h])) * rr[h];
         }
         if (i < P.n_rows) {
             float* pr = ws + P.o_rz + (size_t)sl * d * P.n_rows + i;
 #pragma unroll
             for (int k = 0; k < DP; ++k)
-                if (k < d) pr[(size_t)k * P.n_rows] = acc[k] * (2.f * LN2);
+                if (k < d) pr[(size_t)k * P.n_rows] = (k & 1 ? acc[k / 2].y : acc[k / 2].x) * (2.f * LN2);
         }
     } else {
         if (bx * PB >= P.n_cols || (int)blockIdx.y >= P.NR) return;
@@ -244,31 +332,38 @@ __global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const
         __syncthreads();
         const int j = bx * PB + threadIdx.x;
         const int jc = min(j, P.n_cols - 1);
-        float gj[DP], wj[DP], aj[DP], ag[DP], av[DP];
+        f2 gj[DP / 2], wj[DP / 2], aj[DP / 2], ag[DP / 2], av[DP / 2];
 #pragma unroll
         for (int k = 0; k < DP; ++k) {
             const float vv = k < d ? v[(size_t)jc * d + k] : 1.f;
-            gj[k] = k < d ? g[(size_t)jc * d + k] : 0.f;
-            wj[k] = k < d ? (0.5f * LOG2E) / vv : 0.f;
-            aj[k] = k < d ? (-0.5f * LOG2E) * (LOG2PI + logf(vv)) : 0.f;
-            ag[k] = 0.f; av[k] = 0.f;
+            const float g_ = k < d ? g[(size_t)jc * d + k] : 0.f;
+            const float w_ = k < d ? (0.5f * LOG2E) / vv : 0.f;
+            const float a_ = k < d ? (-0.5f * LOG2E) * (LOG2PI + logf(vv)) : 0.f;
+            if (k & 1) { gj[k / 2].y = g_; wj[k / 2].y = w_; aj[k / 2].y = a_; }
+            else { gj[k / 2].x = g_; wj[k / 2].x = w_; aj[k / 2].x = a_; }
         }
+#pragma unroll
+        for (int h = 0; h < DP / 2; ++h) { ag[h] = splat(0.f); av[h] = splat(0.f); }
+        const f2 cQ2 = splat(cQ), half2 = splat(0.5f), nln2 = splat(-LN2);
         for (int i = 0; i < ni; ++i) {
-            float tt[DP], rr[DP];
-            float S = 0.f;
+            const f2* Zi = reinterpret_cast<const f2*>(Z + i * DP);
+            const f2* Li = reinterpret_cast<const f2*>(LK + i * DP);
+            f2 tt[DP / 2], rr[DP / 2], uu[DP / 2];
+            f2 S2 = splat(0.f);
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float dq = Z[i * DP + k] - gj[k];
-                rr[k] = dq * wj[k];
-                tt[k] = aj[k] - dq * rr[k];
-                S += tt[k];
+            for (int h = 0; h < DP / 2; ++h) {
+                const f2 dq = Zi[h] - gj[h];
+                rr[h] = dq * wj[h];
+                uu[h] = dq * rr[h];                                // dq^2 / v * log2(e) / 2
+                tt[h] = aj[h] - uu[h];
+                S2 += tt[h];
             }
-            const float Pij = cP * fexp2(S - LSs[i]);
+            const f2 Pij = splat(cP * fexp2(S2.x + S2.y - LSs[i]));
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float wt = Pij + cQ * fexp2(tt[k] - LK[i * DP + k]);
-                ag[k] += wt * rr[k];
-                av[k] -= wt * (0.5f + LN2 * (tt[k] - aj[k]));      // -1/2 (1 - dq^2 / v),  dq^2 / v = -2 ln2 (T2 - A2)
+            for (int h = 0; h < DP / 2; ++h) {
+                const f2 wt = Pij + cQ2 * fexp2(tt[h] - Li[h]);
+                ag[h] += wt * rr[h];
+                av[h] -= wt * (half2 + nln2 * uu[h]);              // -1/2 (1 - dq^2 / v),  dq^2 / v = 2 ln2 * uu
             }
         }
         if (j < P.n_cols) {
@@ -276,7 +371,10 @@ __global__ __launch_bounds__(PB) void k_pair_grads(PairGeom P, IvaeCoef C, const
             float* pv = ws + P.o_cv + (size_t)rs * d * P.n_cols + j;
 #pragma unroll
             for (int k = 0; k < DP; ++k)
-                if (k < d) { pg[(size_t)k * P.n_cols] = ag[k] * (2.f * LN2); pv[(size_t)k * P.n_cols] = av[k]; }
+                if (k < d) {
+                    pg[(size_t)k * P.n_cols] = (k & 1 ? ag[k / 2].y : ag[k / 2].x) * (2.f * LN2);
+                    pv[(size_t)k * P.n_cols] = k & 1 ? av[k / 2].y : av[k / 2].x;
+                }
         }
     }
 }
@@ -313,9 +411,10 @@ static hipError_t launch_sliced(const PairGeom& P, const IvaeCoef& C, float logM
     const int d = P.d;
     const int rb = (P.n_rows + PB - 1) / PB, cb = (P.n_cols + PB - 1) / PB;
     const size_t sm_cols = (size_t)3 * P.CS * DP * sizeof(float);
+    const size_t sm_stats = sm_cols + (size_t)(P.CS + PB + 64) * sizeof(float);       // + slice_refs' scratch
     const size_t sm_rows = (size_t)(2 * P.RS * DP + P.RS) * sizeof(float);
     const int nm = P.n_models;
-    hipLaunchKernelGGL(k_pair_stats<DP>, dim3(rb * nm, P.NS), dim3(PB), sm_cols, st, P, z, g, v, ws, rb);
+    hipLaunchKernelGGL(k_pair_stats<DP>, dim3(rb * nm, P.NS), dim3(PB), sm_stats, st, P, z, g, v, ws, rb);
     hipLaunchKernelGGL(k_pair_combine, dim3(rb * nm, d + 1), dim3(PB), 0, st, P, ws, lse_s, lse_k, rb);
     const int gx = rb > cb ? rb : cb, gy = P.NS > P.NR ? P.NS : P.NR;
     hipLaunchKernelGGL(k_pair_grads<DP>, dim3(gx * nm, gy, 2), dim3(PB), sm_cols > sm_rows ? sm_cols : sm_rows, st, P, C, z, g, v,
@@ -369,7 +468,7 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_small(int n_rows, int n_cols,
             a2 = (-0.5f * LOG2E) * (LOG2PI + logf(vv));
         }
         if (k < d && j < n_rows) zz = z[(size_t)j * d + k];
-        G[e] = gg; W2[e] = w2; A2[e] = a2; Z[e] = zz;
+        G[e] = gg; W2[e] = w2; A2[e] = a2; Z[e] = zz; LK[e] = 0.f;       // (LK: the padded k stay 0)
     }
     __syncthreads();
 
@@ -382,30 +481,19 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_small(int n_rows, int n_cols,
     {
         float m[DP], s[DP];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) { m[k] = NEG_BIG; s[k] = 0.f; }
-        float mS = NEG_BIG, sS = 0.f;
-        for (int j = j0; j < j1; ++j) {
-            float S = 0.f;
+        for (int k = 0; k < DP; ++k) m[k] = NEG_BIG;
+        float mS = NEG_BIG, sS;
+        for (int j = j0; j < j1; ++j) {          // references: the largest A2 of the wave's columns (see PAIR_TINY)
+            float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float dq = zi[k] - G[j * DP + k];
-                const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
-                m[k] = fmaxf(m[k], t);
-                S += t;
-            }
-            mS = fmaxf(mS, S);
+            for (int k = 0; k < DP; ++k) { m[k] = fmaxf(m[k], A2[j * DP + k]); a += A2[j * DP + k]; }
+            mS = fmaxf(mS, a);
         }
-        for (int j = j0; j < j1; ++j) {
-            float S = 0.f;
+        row_stats_fast<DP>(zi, G, W2, A2, j0, j1, m, s, mS, sS);
+        bool tiny = sS < PAIR_TINY;
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float dq = zi[k] - G[j * DP + k];
-                const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
-                s[k] += fexp2(t - m[k]);
-                S += t;
-            }
-            sS += fexp2(S - mS);
-        }
+        for (int k = 0; k < DP; ++k) tiny |= s[k] < PAIR_TINY;
+        if (__any(tiny)) row_stats_exact<DP>(zi, G + j0 * DP, W2 + j0 * DP, A2 + j0 * DP, max(j1 - j0, 0), m, s, mS, sS);
 #pragma unroll
         for (int k = 0; k < DP; ++k) { pm[(p * (DP + 1) + k) * PSM + l] = m[k]; ps[(p * (DP + 1) + k) * PSM + l] = s[k]; }
         pm[(p * (DP + 1) + DP) * PSM + l] = mS;
@@ -437,54 +525,74 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_small(int n_rows, int n_cols,
 
     // ---- stage 3a: row role -> rz partials of the wave's columns
     {
-        float lk[DP], acc[DP];
+        f2 z2[DP / 2], lk[DP / 2], acc[DP / 2];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) { lk[k] = k < d ? LK[ic * DP + k] * LOG2E : 0.f; acc[k] = 0.f; }
+        for (int h = 0; h < DP / 2; ++h) {
+            z2[h] = f2{zi[2 * h], zi[2 * h + 1]};
+            lk[h] = f2{2 * h < d ? LK[ic * DP + 2 * h] * LOG2E : 0.f, 2 * h + 1 < d ? LK[ic * DP + 2 * h + 1] * LOG2E : 0.f};
+            acc[h] = splat(0.f);
+        }
         const float LSi = LS[ic] * LOG2E;
+        const f2 cQ2 = splat(cQ);
         for (int j = j0; j < j1; ++j) {
-            float tt[DP], rr[DP];
-            float S = 0.f;
+            const f2* Gj = reinterpret_cast<const f2*>(G + j * DP);
+            const f2* Wj = reinterpret_cast<const f2*>(W2 + j * DP);
+            const f2* Aj = reinterpret_cast<const f2*>(A2 + j * DP);
+            f2 tt[DP / 2], rr[DP / 2];
+            f2 S2 = splat(0.f);
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float dq = zi[k] - G[j * DP + k];
-                rr[k] = dq * W2[j * DP + k];
-                tt[k] = A2[j * DP + k] - dq * rr[k];
-                S += tt[k];
+            for (int h = 0; h < DP / 2; ++h) {
+                const f2 dq = z2[h] - Gj[h];
+                rr[h] = dq * Wj[h];
+                tt[h] = Aj[h] - dq * rr[h];
+                S2 += tt[h];
             }
-            const float Pij = cP * fexp2(S - LSi);
+            const f2 Pij = splat(cP * fexp2(S2.x + S2.y - LSi));
 #pragma unroll
-            for (int k = 0; k < DP; ++k) acc[k] -= (Pij + cQ * fexp2(tt[k] - lk[k])) * rr[k];
+            for (int h = 0; h < DP / 2; ++h) acc[h] -= (Pij + cQ2 * fexp2(tt[h] - lk[h])) * rr[h];
         }
 #pragma unroll
-        for (int k = 0; k < DP; ++k) pr[(p * DP + k) * PSM + l] = acc[k] * (2.f * LN2);
+        for (int k = 0; k < DP; ++k) pr[(p * DP + k) * PSM + l] = (k & 1 ? acc[k / 2].y : acc[k / 2].x) * (2.f * LN2);
     }
     // ---- stage 3b: column role (lane = column l) -> cg, cv partials of the wave's rows
     {
         const int jc = min(l, n_cols - 1);
         const int i0 = PSQ * p, i1 = min(i0 + PSQ, n_rows);
-        float gj[DP], wj[DP], aj[DP], ag[DP], av[DP];
+        f2 gj[DP / 2], wj[DP / 2], aj[DP / 2], ag[DP / 2], av[DP / 2];
 #pragma unroll
-        for (int k = 0; k < DP; ++k) { gj[k] = G[jc * DP + k]; wj[k] = W2[jc * DP + k]; aj[k] = A2[jc * DP + k]; ag[k] = 0.f; av[k] = 0.f; }
+        for (int h = 0; h < DP / 2; ++h) {
+            gj[h] = *reinterpret_cast<const f2*>(G + jc * DP + 2 * h);
+            wj[h] = *reinterpret_cast<const f2*>(W2 + jc * DP + 2 * h);
+            aj[h] = *reinterpret_cast<const f2*>(A2 + jc * DP + 2 * h);
+            ag[h] = splat(0.f); av[h] = splat(0.f);
+        }
+        const f2 cQ2 = splat(cQ), half2 = splat(0.5f), nln2 = splat(-LN2), l2e = splat(LOG2E);
         for (int i = i0; i < i1; ++i) {
-            float tt[DP], rr[DP];
-            float S = 0.f;
+            const f2* Zi = reinterpret_cast<const f2*>(Z + i * DP);
+            const f2* Li = reinterpret_cast<const f2*>(LK + i * DP);
+            f2 tt[DP / 2], rr[DP / 2], uu[DP / 2];
+            f2 S2 = splat(0.f);
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float dq = Z[i * DP + k] - gj[k];
-                rr[k] = dq * wj[k];
-                tt[k] = aj[k] - dq * rr[k];
-                S += tt[k];
+            for (int h = 0; h < DP / 2; ++h) {
+                const f2 dq = Zi[h] - gj[h];
+                rr[h] = dq * wj[h];
+                uu[h] = dq * rr[h];
+                tt[h] = aj[h] - uu[h];
+                S2 += tt[h];
             }
-            const float Pij = cP * fexp2(S - LS[i] * LOG2E);
+            const f2 Pij = splat(cP * fexp2(S2.x + S2.y - LS[i] * LOG2E));
 #pragma unroll
-            for (int k = 0; k < DP; ++k) {
-                const float wt = Pij + cQ * fexp2(tt[k] - (k < d ? LK[i * DP + k] * LOG2E : 0.f));
-                ag[k] += wt * rr[k];
-                av[k] -= wt * (0.5f + LN2 * (tt[k] - aj[k]));
+            for (int h = 0; h < DP / 2; ++h) {
+                const f2 wt = Pij + cQ2 * fexp2(tt[h] - Li[h] * l2e);
+                ag[h] += wt * rr[h];
+                av[h] -= wt * (half2 + nln2 * uu[h]);
             }
         }
 #pragma unroll
-        for (int k = 0; k < DP; ++k) { pg[(p * DP + k) * PSM + l] = ag[k] * (2.f * LN2); pv[(p * DP + k) * PSM + l] = av[k]; }
+        for (int k = 0; k < DP; ++k) {
+            pg[(p * DP + k) * PSM + l] = (k & 1 ? ag[k / 2].y : ag[k / 2].x) * (2.f * LN2);
+            pv[(p * DP + k) * PSM + l] = k & 1 ? av[k / 2].y : av[k / 2].x;
+        }
     }
     __syncthreads();
 
