@@ -9,7 +9,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int MODE>
-__global__ __launch_bounds__(1024) void k(float* out, unsigned long long* t, float s) {
+__global__ __launch_bounds__(1024) void k(float* out, unsigned long long* t, float s, int reps) {
     f2 a[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = f2{threadIdx.x * 1e-3f + i, threadIdx.x * 2e-3f + i};
@@ -17,6 +17,7 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* t, flo
     __syncthreads();
     unsigned long long t0, t1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int r = 0; r < reps; ++r)
 #pragma unroll
     for (int i = 0; i < 128; ++i) {
 #pragma unroll
@@ -44,7 +45,7 @@ template <int MODE>
 void run(const char* name, int threads) {
     float* out; unsigned long long* t;
     hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&t, 256 * 16 * 8);
-    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, t, 0.999f);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, t, 0.999f, 1);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(256 * 16);
     hipMemcpy(h.data(), t, 256 * 16 * 8, hipMemcpyDeviceToHost);
@@ -54,6 +55,18 @@ void run(const char* name, int threads) {
     const double wps = waves / 4.0;
     printf("%-22s %d waves/SIMD: %8.0f cycles per wave for 1024 instr -> %.2f cycles per instr per wave, %.2f SIMD cycles per instr\n",
            name, waves / 4, m, m / 1024, m / 1024 / wps);
+    // the same stream 64 times over, whole chip, timed by events: cycles / wall time = the clock the chip holds under this load
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, t, 0.999f, 64);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(threads), 0, 0, out, t, 0.999f, 64);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h.data(), t, 256 * 16 * 8, hipMemcpyDeviceToHost);
+    double m2 = 0; for (int b = 0; b < 256; ++b) for (int w = 0; w < waves; ++w) m2 += h[b * 16 + w];
+    m2 /= 256.0 * waves;
+    printf("    x64, 256 workgroups: %.0f cycles in %.1f us -> %.2f GHz\n", m2, ms * 1e3, m2 / (ms * 1e3) / 1e3);
     hipFree(out); hipFree(t);
 }
 
