@@ -82,11 +82,6 @@ __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fexp2(f2 x) { return f2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 __device__ __forceinline__ f2 splat(float x) { return f2{x, x}; }
-// A log-sum-exp needs a reference that is not below the largest term.  The exact maximum costs a whole extra pass over
-// the columns; T2 <= A2 (the quadratic term only lowers it), so the largest A2 of the columns walked -- known without
-// looking at the row -- is a valid reference.  It can be far above the true maximum only for a row that is far from every
-// column, and then the sum underflows: a sum below PAIR_TINY sends the wave through the exact two-pass walk instead.
-#define PAIR_TINY 1e-30f
 
 // Column constants of slice [j0, j0+nj) -> LDS, three (nj, DP) arrays.
 template <int DP>
@@ -105,72 +100,32 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ g, const fl
     }
 }
 
-// Reference values of a staged slice: U[k] = max_j A2[j][k] (k < DP), U[DP] = max_j sum_k A2[j][k].  AS: (nj) scratch,
-// part: (4, 64) scratch, all in LDS; ends with a barrier.  PB = 256 threads.
+// Statistics of one row over staged columns [j0, j1): the exact maxima first (a log-sum-exp reference that is merely an
+// upper bound -- the largest A2 of the slice, which would save this pass -- underflows for a row that is far from every
+// column of the slice relative to the columns' variances: every trained encoder; built and measured in round 3, then
+// dropped), then the sums of exp2(T2 - max); packed over k pairs.  T2 = A2 - dq * (dq * W2): the form the gradient walks use.
 template <int DP>
-__device__ __forceinline__ void slice_refs(const float* A2, int nj, float* AS, float* part, float* U) {
-    static_assert(DP <= 63, "one lane per latent dimension and one for the sum");
-    for (int j = threadIdx.x; j < nj; j += PB) {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) a += A2[j * DP + k];
-        AS[j] = a;
-    }
-    __syncthreads();
-    const int k = threadIdx.x & 63, pt = threadIdx.x >> 6;
-    float mx = NEG_BIG;
-    if (k <= DP)
-        for (int j = pt; j < nj; j += PB / 64) mx = fmaxf(mx, k < DP ? A2[j * DP + k] : AS[j]);
-    part[pt * 64 + k] = mx;
-    __syncthreads();
-    if (threadIdx.x <= DP) {
-        float m = part[threadIdx.x];
-#pragma unroll
-        for (int p = 1; p < PB / 64; ++p) m = fmaxf(m, part[p * 64 + threadIdx.x]);
-        U[threadIdx.x] = m;
-    }
-    __syncthreads();
-}
-
-// Exact two-pass statistics of one row over staged columns [0, nj): the fallback of the walks below.
-template <int DP>
-__device__ __noinline__ void row_stats_exact(const float* zi, const float* G, const float* W2, const float* A2, int nj,
-                                             float* m, float* s, float& mS, float& sS) {
-#pragma unroll
-    for (int k = 0; k < DP; ++k) { m[k] = NEG_BIG; s[k] = 0.f; }
-    mS = NEG_BIG; sS = 0.f;
-    for (int j = 0; j < nj; ++j) {
-        float S = 0.f;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) {
-            const float dq = zi[k] - G[j * DP + k];
-            const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
-            m[k] = fmaxf(m[k], t);
-            S += t;
-        }
-        mS = fmaxf(mS, S);
-    }
-    for (int j = 0; j < nj; ++j) {
-        float S = 0.f;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) {
-            const float dq = zi[k] - G[j * DP + k];
-            const float t = A2[j * DP + k] - dq * dq * W2[j * DP + k];
-            s[k] += fexp2(t - m[k]);
-            S += t;
-        }
-        sS += fexp2(S - mS);
-    }
-}
-
-// One pass: sums of exp2(T2 - reference) with the references m[k], mS given (slice_refs); packed over k pairs.
-template <int DP>
-__device__ __forceinline__ void row_stats_fast(const float* zi, const float* G, const float* W2, const float* A2, int j0, int j1,
-                                               const float* m, float* s, float mS, float& sS) {
+__device__ __forceinline__ void row_stats(const float* zi, const float* G, const float* W2, const float* A2, int j0, int j1,
+                                          float* m, float* s, float& mS, float& sS) {
     static_assert(DP % 2 == 0, "pairs of latent dimensions");
     f2 z2[DP / 2], m2[DP / 2], s2[DP / 2];
 #pragma unroll
-    for (int h = 0; h < DP / 2; ++h) { z2[h] = f2{zi[2 * h], zi[2 * h + 1]}; m2[h] = f2{m[2 * h], m[2 * h + 1]}; s2[h] = splat(0.f); }
+    for (int h = 0; h < DP / 2; ++h) { z2[h] = f2{zi[2 * h], zi[2 * h + 1]}; m2[h] = splat(NEG_BIG); s2[h] = splat(0.f); }
+    float mx = NEG_BIG;
+    for (int j = j0; j < j1; ++j) {
+        const f2* Gj = reinterpret_cast<const f2*>(G + j * DP);
+        const f2* Wj = reinterpret_cast<const f2*>(W2 + j * DP);
+        const f2* Aj = reinterpret_cast<const f2*>(A2 + j * DP);
+        f2 S2 = splat(0.f);
+#pragma unroll
+        for (int h = 0; h < DP / 2; ++h) {
+            const f2 dq = z2[h] - Gj[h];
+            const f2 t = Aj[h] - dq * (dq * Wj[h]);
+            m2[h] = f2{fmaxf(m2[h].x, t.x), fmaxf(m2[h].y, t.y)};
+            S2 += t;
+        }
+        mx = fmaxf(mx, S2.x + S2.y);
+    }
     float acc = 0.f;
     for (int j = j0; j < j1; ++j) {
         const f2* Gj = reinterpret_cast<const f2*>(G + j * DP);
@@ -180,15 +135,15 @@ __device__ __forceinline__ void row_stats_fast(const float* zi, const float* G, 
 #pragma unroll
         for (int h = 0; h < DP / 2; ++h) {
             const f2 dq = z2[h] - Gj[h];
-            const f2 t = Aj[h] - dq * dq * Wj[h];
+            const f2 t = Aj[h] - dq * (dq * Wj[h]);
             s2[h] += fexp2(t - m2[h]);
             S2 += t;
         }
-        acc += fexp2(S2.x + S2.y - mS);
+        acc += fexp2(S2.x + S2.y - mx);
     }
 #pragma unroll
-    for (int h = 0; h < DP / 2; ++h) { s[2 * h] = s2[h].x; s[2 * h + 1] = s2[h].y; }
-    sS = acc;
+    for (int h = 0; h < DP / 2; ++h) { m[2 * h] = m2[h].x; m[2 * h + 1] = m2[h].y; s[2 * h] = s2[h].x; s[2 * h + 1] = s2[h].y; }
+    mS = mx; sS = acc;
 }
 
 // Per-slice statistics: max and sum-of-exp2 over the slice's columns, for every k and for the sum over k.
@@ -201,21 +156,15 @@ __global__ __launch_bounds__(PB) void k_pair_stats(PairGeom P, const float* __re
     z += mo; g += mo; v += mo; ws += mo;
     const int d = P.d, sl = blockIdx.y, j0 = sl * P.CS, nj = min(P.CS, P.n_cols - j0);
     float* G = sm; float* W2 = G + P.CS * DP; float* A2 = W2 + P.CS * DP;
-    float* AS = A2 + P.CS * DP; float* part = AS + P.CS; float* U = part + PB;
     stage_cols<DP>(g, v, j0, nj, d, G, W2, A2);
     __syncthreads();
-    slice_refs<DP>(A2, nj, AS, part, U);
     const int i = bx * PB + threadIdx.x;
     const int ic = min(i, P.n_rows - 1);
     float zi[DP], m[DP], s[DP];
 #pragma unroll
-    for (int k = 0; k < DP; ++k) { zi[k] = k < d ? z[(size_t)ic * d + k] : 0.f; m[k] = U[k]; }
-    float mS = U[DP], sS;
-    row_stats_fast<DP>(zi, G, W2, A2, 0, nj, m, s, mS, sS);
-    bool tiny = sS < PAIR_TINY;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) tiny |= s[k] < PAIR_TINY;
-    if (__any(tiny)) row_stats_exact<DP>(zi, G, W2, A2, nj, m, s, mS, sS);       // (wave-uniform branch)
+    for (int k = 0; k < DP; ++k) zi[k] = k < d ? z[(size_t)ic * d + k] : 0.f;
+    float mS, sS;
+    row_stats<DP>(zi, G, W2, A2, 0, nj, m, s, mS, sS);
     if (i < P.n_rows) {
         float* pm = ws + P.o_pm + (size_t)sl * (d + 1) * P.n_rows + i;
         float* ps = ws + P.o_ps + (size_t)sl * (d + 1) * P.n_rows + i;
@@ -411,10 +360,9 @@ static hipError_t launch_sliced(const PairGeom& P, const IvaeCoef& C, float logM
     const int d = P.d;
     const int rb = (P.n_rows + PB - 1) / PB, cb = (P.n_cols + PB - 1) / PB;
     const size_t sm_cols = (size_t)3 * P.CS * DP * sizeof(float);
-    const size_t sm_stats = sm_cols + (size_t)(P.CS + PB + 64) * sizeof(float);       // + slice_refs' scratch
     const size_t sm_rows = (size_t)(2 * P.RS * DP + P.RS) * sizeof(float);
     const int nm = P.n_models;
-    hipLaunchKernelGGL(k_pair_stats<DP>, dim3(rb * nm, P.NS), dim3(PB), sm_stats, st, P, z, g, v, ws, rb);
+    hipLaunchKernelGGL(k_pair_stats<DP>, dim3(rb * nm, P.NS), dim3(PB), sm_cols, st, P, z, g, v, ws, rb);
     hipLaunchKernelGGL(k_pair_combine, dim3(rb * nm, d + 1), dim3(PB), 0, st, P, ws, lse_s, lse_k, rb);
     const int gx = rb > cb ? rb : cb, gy = P.NS > P.NR ? P.NS : P.NR;
     hipLaunchKernelGGL(k_pair_grads<DP>, dim3(gx * nm, gy, 2), dim3(PB), sm_cols > sm_rows ? sm_cols : sm_rows, st, P, C, z, g, v,
@@ -480,20 +428,8 @@ __global__ __launch_bounds__(64 * NWV) void k_pair_small(int n_rows, int n_cols,
     for (int k = 0; k < DP; ++k) zi[k] = Z[ic * DP + k];
     {
         float m[DP], s[DP];
-#pragma unroll
-        for (int k = 0; k < DP; ++k) m[k] = NEG_BIG;
-        float mS = NEG_BIG, sS;
-        for (int j = j0; j < j1; ++j) {          // references: the largest A2 of the wave's columns (see PAIR_TINY)
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < DP; ++k) { m[k] = fmaxf(m[k], A2[j * DP + k]); a += A2[j * DP + k]; }
-            mS = fmaxf(mS, a);
-        }
-        row_stats_fast<DP>(zi, G, W2, A2, j0, j1, m, s, mS, sS);
-        bool tiny = sS < PAIR_TINY;
-#pragma unroll
-        for (int k = 0; k < DP; ++k) tiny |= s[k] < PAIR_TINY;
-        if (__any(tiny)) row_stats_exact<DP>(zi, G + j0 * DP, W2 + j0 * DP, A2 + j0 * DP, max(j1 - j0, 0), m, s, mS, sS);
+        float mS, sS;
+        row_stats<DP>(zi, G, W2, A2, j0, j1, m, s, mS, sS);
 #pragma unroll
         for (int k = 0; k < DP; ++k) { pm[(p * (DP + 1) + k) * PSM + l] = m[k]; ps[(p * (DP + 1) + k) * PSM + l] = s[k]; }
         pm[(p * (DP + 1) + DP) * PSM + l] = mS;

@@ -27,10 +27,12 @@ def main():
     cases = [tuple(int(t) for t in a.split(",")) for a in sys.argv[1:]] or [(4096, 4096, 20), (1024, 1024, 5), (64, 64, 5), (64, 64, 10),
                                                                            (512, 4096, 20)]
     cases = [(c[0], c[0], c[1]) if len(c) == 2 else c for c in cases]
-    for R, Cc, d in cases:
+    # every shape twice: broad posteriors (variance ~ 1) and sharp ones (variance ~ 1e-3: a trained encoder; a row is then
+    # dozens of standard deviations away from most columns)
+    for R, Cc, d, vs in [c + (vs,) for c in cases for vs in (1., 1e-3)]:
         gen = torch.Generator(device=dev).manual_seed(1)
         g = torch.randn(Cc, d, generator=gen, device=dev)
-        v = torch.rand(Cc, d, generator=gen, device=dev) * 1.5 + .25
+        v = (torch.rand(Cc, d, generator=gen, device=dev) * 1.5 + .25) * vs
         z = (g + v.sqrt() * torch.randn(Cc, d, generator=gen, device=dev))[:R].contiguous()
         coef = ops.make_coef(a=1., b=1., c=2., d=1., N=1e6, pairwise=True, global_batch=Cc)
         out = ops.pairwise(coef, z, g, v)
@@ -50,7 +52,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = 1e3 * e0.elapsed_time(e1) / n
-        print("rows %5d cols %5d d %2d: %8.1f us per call, %.3f T (i,j,k) elements/s%s" % (R, Cc, d, us, R * Cc * d / us / 1e6, err), flush=True)
+        print("rows %5d cols %5d d %2d var~%g: %8.1f us per call, %.3f T (i,j,k) elements/s%s" % (R, Cc, d, vs, us, R * Cc * d / us / 1e6, err), flush=True)
 
 
 if __name__ == "__main__":
