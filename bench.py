@@ -171,13 +171,13 @@ def other_config_lines(dev, steps=200, cpu=True):
                 "roofline": {"bound": "mfma", "achieved": round(tf, 4), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(tf / FP32_PEAK_TFLOPS, 5), "algorithmic_flops_per_sample": fl}}
         if ck.get("pairwise"):
-            # The B x B x d terms are not a contraction.  Per (i, j, k) the four walks issue ~13 packed-fp32 / plain vector
+            # The B x B x d terms are not a contraction.  Per (i, j, k) the four walks issue 14.5 packed-fp32 / plain vector
             # instructions and 3 v_exp_f32 per lane; with every SIMD busy the chip sustains one packed instruction per
             # 2.07 ns and one v_exp_f32 per 3.4 ns per SIMD (the clock drops to ~1.3 GHz under this load:
             # tools/ubench/valu_pk_rate.hip, profiles/r3_ubench_valu_pk_rate.txt):
-            # 1024 SIMDs x 64 lanes / (13 * 2.07 + 3 * 3.4) ns = 1.77 T elements/s.
+            # 1024 SIMDs x 64 lanes / (14.5 * 2.07 + 3 * 3.4) ns = 1.63 T elements/s.
             el = B * B * dl
-            line["pairwise_roofline"] = {"bound": "valu/exp", "unit": "T (i,j,k) elements/s", "peak": 1.77,
+            line["pairwise_roofline"] = {"bound": "valu/exp", "unit": "T (i,j,k) elements/s", "peak": 1.63,
                                          "elements_per_step": el, "achieved_at_least": round(el / dt / 1e12, 4),
                                          "note": "instruction-issue roof of the pairwise kernels (power-limited rate, measured); "
                                                  "achieved_at_least divides by the WHOLE step's time, MLP kernels included; "
