@@ -1,9 +1,13 @@
 // Pearson cross-correlation block for the MCC metric, float64 arithmetic on fp32 inputs.
 //
 // Replaces np.corrcoef(x, y, rowvar=False)[:d, d:] (metrics/mcc.py:328; torch spec at
-// mcc.py:174-253): two-pass centred moments.  Pass 1: column sums -> means.  Pass 2: centred
-// cross/auto moments, 64-row chunks staged in LDS as doubles, per-block partials reduced in a
-// fixed order (bitwise reproducible).  The Hungarian step (mcc.py:334) stays on the host.
+// mcc.py:174-253): two-pass centred moments.  Pass 1: column sums -> means.  Pass 2: the centred
+// cross moments are the contraction Xc^T Yc over the rows: v_mfma_f64_16x16x4_f64, operands
+// loaded from HBM straight into fragment layout (lane (c, q): row r0 + q, column 16 t + c),
+// converted and centred in registers; the auto moments ride along on the vector unit.  Waves
+// walk 4-row groups grid-strided, per-wave partials meet in LDS and per-block partials in the
+// workspace, both summed in a fixed order (bitwise reproducible for a given n, d).  The
+// Hungarian step (mcc.py:334) stays on the host.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 
@@ -15,13 +19,15 @@ size_t corr_ws_bytes(int64_t n, int d) {
     return sizeof(double) * ((size_t)2 * d + (size_t)CORR_BLOCKS * 2 * d + (size_t)CORR_BLOCKS * ((size_t)d * d + 2 * d));
 }
 
-__global__ __launch_bounds__(256) void k_corr_sums(const float* __restrict__ x, const float* __restrict__ y,
-                                                   int64_t n, int d, double* __restrict__ psum) {
-    // thread c < 2d owns a column; rows strided over blocks.  (d is small: <= 64.)
-    __shared__ double red[256];
+#define CORR_SUM_THREADS 1024
+__global__ __launch_bounds__(CORR_SUM_THREADS) void k_corr_sums(const float* __restrict__ x, const float* __restrict__ y,
+                                                                int64_t n, int d, double* __restrict__ psum) {
+    // thread c < 2d owns a column; rows strided over blocks.  (d is small: <= 64.)  16 waves per CU: the walk is bound by
+    // the bytes in flight
+    __shared__ double red[CORR_SUM_THREADS];
     const int c = threadIdx.x % (2 * d);
     const int sub = threadIdx.x / (2 * d);
-    const int nsub = 256 / (2 * d);
+    const int nsub = CORR_SUM_THREADS / (2 * d);
     double acc = 0.0;
     if (sub < nsub) {
         const float* src = c < d ? x + c : y + (c - d);
@@ -48,102 +54,147 @@ __global__ __launch_bounds__(256) void k_corr_sums(const float* __restrict__ x, 
     }
 }
 
-__global__ void k_corr_mean(const double* __restrict__ psum, int64_t n, int d, int nblk, double* __restrict__ mean) {
-    const int c = threadIdx.x;
-    if (c < 2 * d) {
-        double t = 0.0;
-        for (int b0 = 0; b0 < nblk; b0 += 8) {          // eight partials in flight, summed in block order
-            double p8[8];
+// Sums of the nblk <= CORR_BLOCKS per-block partials of up to 64 consecutive quantities [q0, q0 + cnt) by a 1024-thread
+// workgroup: wave w takes blocks 16 w .. 16 w + 15 (16 loads in flight, 512 contiguous bytes each, summed in block order),
+// lane l quantity q0 + l; the sixteen wave sums meet in LDS and are added in wave order.  Fixed order: deterministic.
+// dst[l] = sum * scale for l < cnt.  (One thread per quantity with eight loads in flight, in ONE workgroup for all
+// quantities, took 57 us at d = 20 -- as long as a streaming pass; the final kernels are therefore grids over the
+// quantities.)  red: (16, 64) doubles of LDS.  Ends with a barrier.
+__device__ __forceinline__ void reduce_partials64(const double* __restrict__ p, int nout, int nblk, int q0, int cnt, double scale,
+                                                  double* red, double* dst) {
+    static_assert(CORR_BLOCKS == 256, "16 waves x 16 blocks");
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = q0 + min(l, cnt - 1);
+    double v[16];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) p8[e] = b0 + e < nblk ? psum[(size_t)(b0 + e) * 2 * d + c] : 0.0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (b0 + e < nblk) t += p8[e];
-        }
-        mean[c] = t / (double)n;
+    for (int e = 0; e < 16; ++e) {
+        const int blk = min(w * 16 + e, nblk - 1);
+        v[e] = p[(size_t)blk * nout + q];
     }
-}
-
-__global__ __launch_bounds__(256) void k_corr_moments(const float* __restrict__ x, const float* __restrict__ y,
-                                                      int64_t n, int d, const double* __restrict__ mean,
-                                                      double* __restrict__ pmom) {
-    extern __shared__ __attribute__((aligned(16))) double tile[];   // CORR_ROWS x (2d+1)
-    const int ld = 2 * d + 1;
-    const int nout = d * d + 2 * d;
-    // every thread keeps up to ceil(nout/256) accumulators; nout <= 64*64+128 -> <= 17
-    double acc[17];
+    double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 17; ++q) acc[q] = 0.0;
-    // the next chunk's elements are requested (into registers) before the current chunk's products run, so the memory
-    // round trip of a chunk hides under the arithmetic of the one before; CORR_ROWS * 2d / 256 <= 32 elements per thread
-    float nxt[32];
-    auto fetch = [&](int64_t r0) {
-        const int nr = (int)((n - r0) < CORR_ROWS ? (n - r0) : CORR_ROWS);
+    for (int e = 0; e < 16; ++e) t += w * 16 + e < nblk ? v[e] : 0.0;
+    red[w * 64 + l] = t;
+    __syncthreads();
+    if (w == 0 && l < cnt) {
+        double tot = 0.0;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const int idx = threadIdx.x + e * 256;
-            const int r = idx / (2 * d), c = idx - r * 2 * d;
-            float val = 0.f;
-            if (idx < CORR_ROWS * 2 * d && r < nr) val = c < d ? x[(r0 + r) * d + c] : y[(r0 + r) * d + (c - d)];
-            nxt[e] = val;
-        }
-    };
-    const int64_t step = (int64_t)gridDim.x * CORR_ROWS;
-    if ((int64_t)blockIdx.x * CORR_ROWS < n) fetch((int64_t)blockIdx.x * CORR_ROWS);
-    for (int64_t r0 = (int64_t)blockIdx.x * CORR_ROWS; r0 < n; r0 += step) {
-        const int nr = (int)((n - r0) < CORR_ROWS ? (n - r0) : CORR_ROWS);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const int idx = threadIdx.x + e * 256;
-            if (idx < CORR_ROWS * 2 * d) {
-                const int r = idx / (2 * d), c = idx - r * 2 * d;
-                tile[r * ld + c] = r < nr ? (double)nxt[e] - mean[c] : 0.0;
-            }
-        }
-        __syncthreads();
-        if (r0 + step < n) fetch(r0 + step);
-#pragma unroll
-        for (int q = 0; q < 17; ++q) {
-            const int o = threadIdx.x + q * 256;
-            if (o < nout) {
-                int ca, cb;
-                if (o < d * d) { ca = o / d; cb = d + (o - ca * d); }
-                else { ca = cb = o - d * d; }
-                double s = 0.0;
-                // rows past the chunk's end are zeros in the tile: a fixed trip count lets the loads of several rows be in flight
-#pragma unroll 8
-                for (int r = 0; r < CORR_ROWS; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
-                acc[q] += s;
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < 17; ++q) {
-        const int o = threadIdx.x + q * 256;
-        if (o < nout) pmom[(size_t)blockIdx.x * nout + o] = acc[q];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_corr_final(const double* __restrict__ pmom, int64_t n, int d, int nblk,
-                                                    double* __restrict__ cc) {
-    extern __shared__ __attribute__((aligned(16))) double mom[];   // d*d + 2d
-    const int nout = d * d + 2 * d;
-    for (int o = threadIdx.x; o < nout; o += 256) {
-        double t = 0.0;
-        for (int b0 = 0; b0 < nblk; b0 += 8) {          // eight partials in flight, summed in block order
-            double p8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) p8[e] = b0 + e < nblk ? pmom[(size_t)(b0 + e) * nout + o] : 0.0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (b0 + e < nblk) t += p8[e];
-        }
-        mom[o] = t / (double)(n - 1);        // np.cov normalisation (cancels, kept for rounding parity)
+        for (int ww = 0; ww < 16; ++ww) tot += red[ww * 64 + l];
+        dst[l] = tot * scale;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < d * d; o += 256) {
-        const int a = o / d, b = o - a * d;
-        double c = mom[o] / sqrt(mom[d * d + a]);
-        c = c / sqrt(mom[d * d + d + b]);
+}
+
+__global__ __launch_bounds__(1024) void k_corr_mean(const double* __restrict__ psum, int64_t n, int d, int nblk, double* __restrict__ mean) {
+    __shared__ double red[16 * 64];
+    const int q0 = blockIdx.x * 64;
+    reduce_partials64(psum, 2 * d, nblk, q0, min(64, 2 * d - q0), 1.0 / (double)n, red, mean + q0);
+}
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// NT = ceil(d / 16) column tiles of x and of y; WAVES per workgroup (NT <= 2: 16, four per SIMD; else 8: the NT*NT
+// accumulator tiles take 8 registers each).  MFMA slots: A[i = c][k = q] = xc[row q][column 16 ta + c],
+// B[k = q][j = c] = yc[row q][column 16 tb + c]; D[i = 4 r + q][j = c] in register pair r (probed on gfx950: the fp64
+// shape interleaves rows where the fp32 16x16x4 shape blocks them).
+template <int NT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __restrict__ x, const float* __restrict__ y,
+                                                            int64_t n, int d, const double* __restrict__ mean,
+                                                            double* __restrict__ pmom) {
+    extern __shared__ __attribute__((aligned(16))) double part[];    // (nout) the block's partial moments
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+    const int nout = d * d + 2 * d;
+    f64x4 acc[NT][NT];
+    double mx[NT], my[NT], sxx[NT], syy[NT];
+    int col[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        col[t] = min(16 * t + c, d - 1);                     // (a clamped column is loaded and zeroed below)
+        mx[t] = mean[col[t]]; my[t] = mean[d + col[t]];
+        sxx[t] = 0.0; syy[t] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+    constexpr int U = 4;                                      // 4-row groups in flight per wave: 2 NT U loads
+    const int64_t ngroups = (n + 3) / 4;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    for (int64_t g0 = (int64_t)blockIdx.x * WAVES + w; g0 < ngroups; g0 += U * stride) {
+        float xv[U][NT], yv[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = min((g0 + u * stride) * 4 + q, n - 1);     // (clamped: zeroed below)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { xv[u][t] = x[row * d + col[t]]; yv[u][t] = y[row * d + col[t]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = (g0 + u * stride) * 4 + q;
+            const bool rok = g0 + u * stride < ngroups && row < n;
+            double a[NT], b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bool ok = rok && 16 * t + c < d;
+                a[t] = ok ? (double)xv[u][t] - mx[t] : 0.0;
+                b[t] = ok ? (double)yv[u][t] - my[t] : 0.0;
+                sxx[t] += a[t] * a[t];
+                syy[t] += b[t] * b[t];
+            }
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NT; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+    }
+    // wave partials -> one LDS block, wave after wave (a fixed order: deterministic).  Cross moments from the accumulators;
+    // auto moments: the four q lanes of a column summed in q order first
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const double vx = sxx[t], vy = syy[t];
+        const double x1 = __shfl(vx, c + 16), x2 = __shfl(vx, c + 32), x3 = __shfl(vx, c + 48);
+        const double y1 = __shfl(vy, c + 16), y2 = __shfl(vy, c + 32), y3 = __shfl(vy, c + 48);
+        sxx[t] = ((vx + x1) + x2) + x3;
+        syy[t] = ((vy + y1) + y2) + y3;
+    }
+    for (int ww = 0; ww < WAVES; ++ww) {
+        if (w == ww) {
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ia = 16 * ta + 4 * r + q, jb = 16 * tb + c;
+                        if (ia < d && jb < d) part[ia * d + jb] = (ww ? part[ia * d + jb] : 0.0) + acc[ta][tb][r];
+                    }
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (q == 0 && 16 * t + c < d) {
+                    const int ox = d * d + 16 * t + c, oy = ox + d;
+                    part[ox] = (ww ? part[ox] : 0.0) + sxx[t];
+                    part[oy] = (ww ? part[oy] : 0.0) + syy[t];
+                }
+        }
+        __syncthreads();
+    }
+    for (int o = threadIdx.x; o < nout; o += 64 * WAVES) pmom[(size_t)blockIdx.x * nout + o] = part[o];
+}
+
+// Workgroup b: correlations of the cross moments o in [64 b, 64 b + 64); it reduces those and (again in every workgroup:
+// 2d more quantities) the auto moments it divides by.
+__global__ __launch_bounds__(1024) void k_corr_final(const double* __restrict__ pmom, int64_t n, int d, int nblk,
+                                                     double* __restrict__ cc) {
+    __shared__ double red[16 * 64];
+    __shared__ double cross[64];
+    __shared__ double autos[128];
+    const int nout = d * d + 2 * d, o0 = blockIdx.x * 64, cnt = min(64, d * d - o0);
+    const double scale = 1.0 / (double)(n - 1);            // np.cov normalisation (cancels in the ratio)
+    reduce_partials64(pmom, nout, nblk, o0, cnt, scale, red, cross);
+    for (int a0 = 0; a0 < 2 * d; a0 += 64) reduce_partials64(pmom, nout, nblk, d * d + a0, min(64, 2 * d - a0), scale, red, autos + a0);
+    if ((int)threadIdx.x < cnt) {
+        const int o = o0 + threadIdx.x, a = o / d, b = o - a * d;
+        double c = cross[threadIdx.x] / sqrt(autos[a]);
+        c = c / sqrt(autos[d + b]);
         cc[o] = fmin(1.0, fmax(-1.0, c));     // np.corrcoef clips to [-1, 1]
     }
 }
@@ -227,19 +278,22 @@ hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks,
 }
 
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st) {
-    static SmemCache cur = {};
     double* mean = ws;
     double* psum = mean + 2 * d;
     double* pmom = psum + (size_t)CORR_BLOCKS * 2 * d;
     int nblk = (int)((n + CORR_ROWS - 1) / CORR_ROWS);
     if (nblk > CORR_BLOCKS) nblk = CORR_BLOCKS;
-    const size_t smem = (size_t)CORR_ROWS * (2 * d + 1) * sizeof(double);          // d = 64: 66048 B, above the default limit
-    hipError_t e = set_smem((const void*)k_corr_moments, (int)smem, cur);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_corr_sums, dim3(nblk), dim3(256), 0, st, x, y, n, d, psum);
-    hipLaunchKernelGGL(k_corr_mean, dim3(1), dim3(128), 0, st, psum, n, d, nblk, mean);
-    hipLaunchKernelGGL(k_corr_moments, dim3(nblk), dim3(256), smem, st, x, y, n, d, mean, pmom);
-    hipLaunchKernelGGL(k_corr_final, dim3(1), dim3(256), (size_t)(d * d + 2 * d) * sizeof(double), st, pmom, n, d, nblk, cc);
+    const size_t smem = (size_t)(d * d + 2 * d) * sizeof(double);          // d = 64: 33 792 B
+    hipLaunchKernelGGL(k_corr_sums, dim3(nblk), dim3(CORR_SUM_THREADS), 0, st, x, y, n, d, psum);
+    hipLaunchKernelGGL(k_corr_mean, dim3((2 * d + 63) / 64), dim3(1024), 0, st, psum, n, d, nblk, mean);
+    switch ((d + 15) / 16) {
+        case 1: hipLaunchKernelGGL((k_corr_moments<1, 16>), dim3(nblk), dim3(1024), smem, st, x, y, n, d, mean, pmom); break;
+        case 2: hipLaunchKernelGGL((k_corr_moments<2, 16>), dim3(nblk), dim3(1024), smem, st, x, y, n, d, mean, pmom); break;
+        case 3: hipLaunchKernelGGL((k_corr_moments<3, 8>), dim3(nblk), dim3(512), smem, st, x, y, n, d, mean, pmom); break;
+        case 4: hipLaunchKernelGGL((k_corr_moments<4, 8>), dim3(nblk), dim3(512), smem, st, x, y, n, d, mean, pmom); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k_corr_final, dim3((d * d + 63) / 64), dim3(1024), 0, st, pmom, n, d, nblk, cc);
     return hipGetLastError();
 }
 
