@@ -49,6 +49,23 @@ def _column_normalised(A):
     return A
 
 
+def _trial_conds(n_iter, d_sources, d_data, dtype):
+    """Condition numbers of n_iter column-normalised uniform matrices: the reference's loop (data.py:100-105: draw,
+    normalise, np.linalg.cond, 10^4 times per mixing layer -- 3 s per dataset at d = 10, 12 s at d = 40) as stacked array
+    operations with the SAME bits: one uniform draw of the whole stack consumes the generator's stream exactly as the
+    n_iter draws do; the column norms reduce over a contiguous last axis, so numpy's pairwise summation sees each
+    column as the loop's 1-D `.sum()` does; np.linalg.cond of a stack calls the same LAPACK routine per matrix
+    (tests/test_data_cpu.py compares it with the loop)."""
+    out = []
+    for i0 in range(0, n_iter, 2048):                                  # chunks: bounded memory at large d
+        m = min(2048, n_iter - i0)
+        A = np.random.uniform(-1, 1, (m, d_sources, d_data)).astype(dtype)
+        sq = np.ascontiguousarray((A ** 2).transpose(0, 2, 1))            # (m, column, row): rows contiguous
+        A /= np.sqrt(sq.sum(axis=-1))[:, None, :]
+        out.append(np.linalg.cond(A))
+    return np.concatenate(out)
+
+
 def generate_mixing_matrix(d_sources, d_data=None, lin_type='uniform', cond_threshold=25, n_iter_4_cond=None,
                            dtype=np.float32, staircase=False):
     """Well-conditioned random mixing matrix (data.py:69-131)."""
@@ -62,10 +79,7 @@ def generate_mixing_matrix(d_sources, d_data=None, lin_type='uniform', cond_thre
     if n_iter_4_cond is None:
         thresh = cond_threshold
     else:
-        conds = []
-        for _ in range(int(n_iter_4_cond)):
-            conds.append(np.linalg.cond(_column_normalised(np.random.uniform(-1, 1, (d_sources, d_data)).astype(dtype))))
-        thresh = np.percentile(conds, 25)
+        thresh = np.percentile(_trial_conds(int(n_iter_4_cond), d_sources, d_data, dtype), 25)
 
     def draw():
         if not staircase:

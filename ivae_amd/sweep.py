@@ -54,17 +54,34 @@ def device_datasets(n_models, n_seg, n_per_seg, d, seeds, device):
     return torch.stack(xs).contiguous(), u.unsqueeze(0).expand(n_models, N, n_seg).contiguous(), torch.stack(ss).contiguous()
 
 
-def host_datasets(n_seg, n_per_seg, d, seeds, device):
+def _host_dataset(job):
+    n_seg, n_per_seg, d, sd = job
+    S, X, U, _, _ = generate_data(n_per_seg, n_seg, d, n_layers=3, seed=int(sd), prior='gauss', activation='lrelu',
+                                  repeat_linearity=True)
+    return tuple(np.ascontiguousarray(a, np.float32) for a in (X, U, S))
+
+
+def host_datasets_numpy(n_seg, n_per_seg, jobs, workers=None):
     """The bit-exact host generator (ivae_amd.data.generate_data == data/data.py:200-304, repeat_linearity=True as
-    data.py:369), one dataset per run seed."""
-    xs, us, ss = [], [], []
-    for sd in seeds:
-        S, X, U, _, _ = generate_data(n_per_seg, n_seg, d, n_layers=3, seed=int(sd), prior='gauss', activation='lrelu',
-                                      repeat_linearity=True)
-        xs.append(torch.from_numpy(np.ascontiguousarray(X, np.float32)))
-        us.append(torch.from_numpy(np.ascontiguousarray(U, np.float32)))
-        ss.append(torch.from_numpy(np.ascontiguousarray(S, np.float32)))
-    return torch.stack(xs).to(device), torch.stack(us).to(device), torch.stack(ss).to(device)
+    data.py:369), one dataset per (d, seed) job -> {(d, seed): (X, U, S)}.  The datasets are independent (the generator
+    seeds the legacy numpy stream per dataset), so they are made by a pool of forked workers -- only while this process
+    has not initialised the GPU (a fork of a process that holds a HIP context is not safe); afterwards one by one."""
+    args = [(n_seg, n_per_seg, d, sd) for d, sd in jobs]
+    workers = min(workers or 16, len(args), os.cpu_count() or 1)
+    if workers > 1 and not torch.cuda.is_initialized():
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            out = pool.map(_host_dataset, args, chunksize=1)
+    else:
+        out = [_host_dataset(a) for a in args]
+    return dict(zip(jobs, out))
+
+
+def host_datasets(n_seg, n_per_seg, d, seeds, device, made=None):
+    """One dataset per run seed on the device; `made`: datasets host_datasets_numpy already holds."""
+    made = made or host_datasets_numpy(n_seg, n_per_seg, [(d, sd) for sd in seeds])
+    xs, us, ss = zip(*[made[(d, sd)] for sd in seeds])
+    return tuple(torch.stack([torch.from_numpy(a) for a in t]).to(device) for t in (xs, us, ss))
 
 
 def evaluate_pack(shape, params, x, u, s_true, rows_per_call=8192, seed=0):
@@ -103,7 +120,7 @@ def train_pack(tr, n_models, epochs, steps_per_epoch, lr, patience):
 
 
 def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2, hidden=50, data="host",
-              device=None, rank=0, world=1, log=None, concurrent=True, patience=0, lr_out=None):
+              device=None, rank=0, world=1, log=None, concurrent=True, patience=0, lr_out=None, datasets=None):
     """Runs this rank's share of the (dim, seed) grid; returns (local run ids, local MCCs, seconds spent training,
     training steps x models done).  concurrent: the packs of the different latent dimensions train at the same time, each
     on a HIP stream of its own -- a 64-model pack of the fused kernel occupies 64 of the 256 CUs and a 64-model pack of
@@ -119,12 +136,15 @@ def run_sweep(dims, n_seeds, epochs, n_seg=40, n_per_seg=1000, batch=64, lr=1e-2
     nb = N // batch
     steps = epochs * nb
     packs = []
+    made = None
+    if data == "host":      # `datasets`: what host_datasets_numpy made for these runs before the GPU was initialised (main)
+        made = datasets if datasets is not None else host_datasets_numpy(n_seg, n_per_seg, mine)
     for d in sorted({r[0] for r in mine}):
         idx = [i for i, r in enumerate(mine) if r[0] == d]
         seeds = [mine[i][1] for i in idx]
         shape = ops.ModelShape(d, d, n_seg, hidden, 3, "lrelu", .1)
         if data == "host":
-            x, u, s_true = host_datasets(n_seg, n_per_seg, d, seeds, device)
+            x, u, s_true = host_datasets(n_seg, n_per_seg, d, seeds, device, made)
         else:
             x, u, s_true = device_datasets(len(seeds), n_seg, n_per_seg, d, [1000 * d + s for s in seeds], device)
         fused = ops.train_steps_supported(shape, batch)
@@ -189,16 +209,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dims = [int(t) for t in args.dims.split(",")]
+    t0 = time.perf_counter()
+    made = None
+    if args.data == "host":      # the host generator's worker pool forks: before this process initialises the GPU
+        runs = [(d, s) for d in dims for s in range(args.seeds)]
+        lo, hi = model_range(len(runs), rank, world)
+        made = host_datasets_numpy(args.ns, args.nps, runs[lo:hi], workers=max(1, 16 // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+    t_data = time.perf_counter() - t0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    dims = [int(t) for t in args.dims.split(",")]
-    t0 = time.perf_counter()
     (lo, hi), mcc, t_train, work = run_sweep(dims, args.seeds, args.epochs, args.ns, args.nps, args.batch, args.lr,
                                              data=args.data, device=dev, rank=rank, world=world,
                                              log=lambda s: print(s, flush=True), concurrent=not args.serial,
-                                             patience=None if args.no_scheduler else 0)
+                                             patience=None if args.no_scheduler else 0, datasets=made)
     n_runs = len(dims) * args.seeds
     allm = gather_model_results(torch.from_numpy(mcc).to(dev), n_runs).cpu().numpy()
     stats = torch.tensor([t_train, float(work)], device=dev, dtype=torch.float64)
@@ -221,6 +247,7 @@ def main():
                                    "device stand-in, NOT the reference generator (no condition-number rejection)"),
                           "train_samples_per_s": round(work * args.batch / t_train, 1),
                           "train_seconds_max_over_ranks": round(t_train, 2),
+                          "host_data_seconds": round(t_data, 2),
                           "wall_seconds": round(time.perf_counter() - t0, 2), "mcc": per_dim}))
     if world > 1:
         dist.destroy_process_group()

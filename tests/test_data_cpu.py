@@ -41,3 +41,21 @@ def test_dataset_cache_name_and_keys(tmp_path):
     assert D.dataset_path("r/", 1, 2, 3, 4, 5, 6, 'lap', 'lrelu', True, True) == "r/tcl_1_2_3_4_5_6_lap_lrelu_u_noisy.npz"
     cd = D.ResidentDataset(ds.x.numpy(), ds.u.numpy())                      # no ground truth: s falls back to x
     assert cd.get_dims() == (2, 2, 3) and cd.s is cd.x
+
+
+@pytest.mark.parametrize("ds,dd", [(2, 2), (5, 5), (8, 8), (10, 10), (5, 8), (20, 20), (40, 40)])
+def test_condition_number_trials_are_the_reference_loop_bit_for_bit(ds, dd):
+    """The stacked form of the generator's 10^4 condition-number trials (data.py:100-105) against the loop it replaces:
+    same condition numbers, same generator state afterwards (what keeps every later draw -- the datasets -- bit-exact)."""
+    from ivae_amd import data
+
+    n = 600
+    np.random.seed(100 + ds)
+    want = np.array([np.linalg.cond(data._column_normalised(np.random.uniform(-1, 1, (ds, dd)).astype(np.float32)))
+                     for _ in range(n)])
+    after_loop = np.random.uniform()
+    np.random.seed(100 + ds)
+    got = data._trial_conds(n, ds, dd, np.float32)
+    assert got.dtype == want.dtype and np.array_equal(got, want)
+    assert np.random.uniform() == after_loop
+    assert np.percentile(list(want), 25) == np.percentile(got, 25)
