@@ -112,7 +112,7 @@ class _SeedPack:
         return loss, z
 
 
-def runner(args, config, *, replay=None, trace=None, init_seeds=False):
+def runner(args, config, *, replay=None, trace=None, init_seeds=False, init_perturb=0):
     """runners/ivae.py:13-128.  `args`: data_path, seed, n_sims.  `config`: the yaml keys of configs/*.yaml plus
     `device`.  Returns (perfs, loss_hists, perf_hists).
 
@@ -126,7 +126,9 @@ def runner(args, config, *, replay=None, trace=None, init_seeds=False):
     `replay.eval_eps(seed)` the (N, d_latent) noise of the final full-data sample; `trace` (a dict) receives the
     per-step losses, and per epoch the loss weights and the learning rates after the schedulers' steps; `init_seeds`:
     the model of seed s is drawn after torch.manual_seed(s), i.e. as `main.py --seed s --n-sims 1` draws it, so that
-    recorded single-seed runs of the reference can be replayed as one pack."""
+    recorded single-seed runs of the reference can be replayed as one pack; `init_perturb` = k > 0: every initial
+    parameter is moved by ~1e-6 relative, as tools/make_golden.py moved them for the reference's "twin" runs (a
+    sensitivity probe: 12 500 Adam steps at lr 1e-2 amplify it to a visibly different trajectory)."""
     st = time.time()
     device = torch.device(config.device)
     print('Executing script on: {}\n'.format(device))
@@ -154,6 +156,12 @@ def runner(args, config, *, replay=None, trace=None, init_seeds=False):
         else:
             models.append(cleanVAE(data_dim=d_data, latent_dim=d_latent, hidden_dim=config.hidden_dim,
                                    n_layers=config.n_layers, activation=config.activation, slope=.1).to(device))
+    if init_perturb:
+        pgen = torch.Generator().manual_seed(4242 + int(init_perturb))
+        with torch.no_grad():
+            for model in models:
+                for p in model.parameters():
+                    p.mul_((1 + 1e-6 * torch.randn(p.shape, generator=pgen)).to(device))
     pack = _SeedPack(models, config.lr)
     schedulers = [_ReduceLROnPlateau(opt, factor=0.1, patience=0) for opt in pack.optimizers]
     loss_hists, perf_hists = [[] for _ in seeds], [[] for _ in seeds]
