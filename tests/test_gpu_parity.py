@@ -298,7 +298,8 @@ def test_corr_kernel_matches_numpy_corrcoef(golden_dir):
 
 
 def test_corr_at_the_widest_supported_d():
-    """d = 64: k_corr_moments needs 66 KB of dynamic LDS, above the default 64 KB limit (per-device attribute)."""
+    """d = 64: four column tiles a side in ivae_corr; k_corr_batched needs 66 KB of dynamic LDS, above the default 64 KB
+    limit (per-device attribute)."""
     rng = np.random.RandomState(3)
     x = rng.randn(700, 64).astype(np.float32)
     y = (x @ rng.randn(64, 64).astype(np.float32) * 0.1 + rng.randn(700, 64)).astype(np.float32)
@@ -306,6 +307,20 @@ def test_corr_at_the_widest_supported_d():
     ref = np.corrcoef(x.astype(np.float64), y.astype(np.float64), rowvar=False)[:64, 64:]
     assert np.abs(ops.corr(t(x), t(y)).cpu().numpy() - ref).max() < 1e-12
     assert np.abs(ops.corr_batched(t(x)[None], t(y)[None]).cpu().numpy()[0] - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,d", [(2, 1), (3, 5), (5, 16), (63, 17), (64, 20), (65, 32), (257, 33), (1000, 40), (1027, 48),
+                                 (4099, 49), (70001, 10), (300007, 20)])
+def test_corr_fragment_tiles_and_row_tails(n, d):
+    """The fp64-MFMA moments kernel at every column-tile count (d = 1..64 -> 1..4 tiles, full and ragged), at row counts
+    that are no multiple of the 4-row fragment or of the waves' stride, from fewer rows than one workgroup has waves up to
+    many rounds of all 256 workgroups; non-zero means (the centring is what keeps float64 exact enough)."""
+    rng = np.random.RandomState(n + d)
+    x = (rng.randn(n, d) * rng.uniform(.5, 3, d) + rng.uniform(-50, 50, d)).astype(np.float32)
+    y = (x @ (rng.randn(d, d) * 0.3) + rng.randn(n, d) + 7).astype(np.float32)
+    ref = np.corrcoef(x.astype(np.float64), y.astype(np.float64), rowvar=False)[:d, d:]
+    got = ops.corr(torch.from_numpy(x).to(dev()), torch.from_numpy(y).to(dev())).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-12, (n, d)
 
 
 def test_corr_large_n_property():
