@@ -11,8 +11,8 @@ single-GPU semantics it must reproduce:
   identical fused Adam step on every rank;
 * data-parallel pairwise ELBO (cleanIVAE / cleanVAE / iVAE anneal): T[i,j,k] = log q(z_i | x_j) couples every
   row with every column of the global batch (nets.py:180-182, 466-469), so between forward and backward the
-  ranks all-gather (g, v), run `ivae_pairwise(rows = local, columns = global)`, and all-reduce the column terms
-  (cg, cv) before the usual gradient all-reduce.
+  ranks all-gather (g, v) as one message, run `ivae_pairwise(rows = local, columns = global)`, and reduce-scatter the
+  column terms (cg, cv) -- a rank's backward pass needs only its own rows of them -- before the usual gradient all-reduce.
 
 The gradient vector is 80-190 KB: one collective per step, latency-bound; nothing is bucketed or overlapped.
 """
@@ -60,8 +60,9 @@ class DataParallelELBO:
     make the result equal to the single-GPU full-batch result.
 
     `backend` is the module that launches the kernels (`ivae_amd.ops`; tests substitute an oracle-backed double to
-    exercise the exchange logic on CPU ranks).  The two collectives are methods (`_all_reduce`, `_all_gather_rows`) so that
-    a test double can route them differently (tests/test_gpu_dist.py stages them through host memory for gloo).
+    exercise the exchange logic on CPU ranks).  The collectives are methods (`_all_reduce`, `_all_gather_into`,
+    `_reduce_scatter_into`, and `_all_gather_rows` for shards of unequal length) so that a test double can route them
+    differently (tests/test_gpu_dist.py stages them through host memory for gloo).
 
     The tensors `fwd_bwd` returns as loss and gradient are VIEWS of one persistent buffer (the message of the step's one
     collective): they hold this step's values until the next call overwrites them -- clone what must outlive the step."""
@@ -76,15 +77,39 @@ class DataParallelELBO:
         self.rank, self.world = _world(group)
         self.ws = backend.Workspace()
         self._gl = None          # [gradient | loss]: written by the kernels, all-reduced as one message
+        self._bufs = {}
 
     # -- collectives -----------------------------------------------------------------
+    # Three primitives (a test double routes them through host memory for gloo, tests/test_gpu_dist.py); everything
+    # else in this class is layout.
     def _all_reduce(self, t):
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def _all_gather_into(self, out, t):
+        """out (world * n) <- every rank's t (n), in rank order."""
+        dist.all_gather_into_tensor(out, t, group=self.group)
+
+    def _reduce_scatter_into(self, out, t):
+        """out (n) <- chunk `rank` of the sum over ranks of t (world chunks of n along dim 0).  RCCL has the collective
+        (each rank receives 1/world of what an all-reduce would hand it); gloo does not: all-reduce, keep the own chunk."""
+        if dist.get_backend(self.group) == "nccl":
+            dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self._all_reduce(t)
+            out.copy_(t[self.rank])
+
+    def _scratch(self, name, shape, like):
+        """Persistent exchange buffers: a step allocates nothing once its shapes have been seen."""
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.device != like.device:
+            t = self._bufs[name] = torch.empty(shape, dtype=torch.float32, device=like.device)
+        return t
+
     def _all_gather_rows(self, t, global_batch):
-        """(local rows, d) of every rank -> (global_batch, d), rows in rank order (row_range partition)."""
+        """(local rows, d) of every rank -> (global_batch, d), rows in rank order (row_range partition); shards that
+        differ by a row are padded to the longest."""
         if self.world == 1:
             return t
         sizes = [row_range(global_batch, r, self.world) for r in range(self.world)]
@@ -94,6 +119,36 @@ class DataParallelELBO:
         parts = [torch.empty_like(pad) for _ in range(self.world)]
         dist.all_gather(parts, pad, group=self.group)
         return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], 0)
+
+    def _gather_cols(self, g, v, global_batch):
+        """(g, v) of the local rows -> (g, v) of the global batch.  Equal shards (the usual case): ONE all-gather of the
+        stacked pair straight into a persistent buffer and one copy that puts the ranks' row blocks side by side."""
+        if self.world == 1:
+            return g, v
+        if global_batch % self.world:
+            return self._all_gather_rows(g, global_batch).contiguous(), self._all_gather_rows(v, global_batch).contiguous()
+        Bl, dl = g.shape
+        msg = torch.stack([g, v])                                          # (2, Bl, dl)
+        got = self._scratch("gather", (self.world, 2, Bl, dl), g)
+        self._all_gather_into(got.view(-1), msg.view(-1))
+        gv = self._scratch("cols", (2, self.world * Bl, dl), g)
+        gv.view(2, self.world, Bl, dl).copy_(got.permute(1, 0, 2, 3))
+        return gv[0], gv[1]
+
+    def _reduce_cols(self, cg, cv, lo, hi, global_batch):
+        """Column terms (global_batch, dl) summed over the ranks -> the rows [lo, hi) this rank's backward pass needs.
+        Equal shards: a reduce-scatter of the stacked pair (chunk r = rank r's rows of both terms)."""
+        if self.world == 1:
+            return cg[lo:hi], cv[lo:hi]
+        if global_batch % self.world:
+            cgv = torch.stack([cg, cv])
+            self._all_reduce(cgv)                                          # both column terms in one collective
+            return cgv[0, lo:hi], cgv[1, lo:hi]
+        Bl, dl = hi - lo, cg.shape[1]
+        msg = torch.stack([cg.view(self.world, Bl, dl), cv.view(self.world, Bl, dl)], 1)     # (world, 2, Bl, dl)
+        out = self._scratch("scatter", (2, Bl, dl), cg)
+        self._reduce_scatter_into(out.view(-1), msg.view(self.world, -1))
+        return out[0], out[1]
 
     # -- one step ---------------------------------------------------------------------
     def fwd_bwd(self, params, x, u, eps, global_batch, a=1., b=1., c=1., d=1., N=1., pairwise=False):
@@ -113,20 +168,14 @@ class DataParallelELBO:
         else:
             Bl, dl = hi - lo, sh.latent_dim
             z = be.forward(sh, coef, params, x, u, eps, self.ws)
-            g_all = self._all_gather_rows(self.ws.view('g', Bl, dl), global_batch)
-            v_all = self._all_gather_rows(self.ws.view('v', Bl, dl), global_batch)
+            g_all, v_all = self._gather_cols(self.ws.view('g', Bl, dl), self.ws.view('v', Bl, dl), global_batch)
             # the row-side results land in the workspace rows ivae_backward reads; only the column sums travel
             into = {k: self.ws.view(k, Bl) for k in ('lq', 'lqi', 'lse_s')}
             into.update({k: self.ws.view(k, Bl, dl) for k in ('lse_k', 'rz')})
-            pw = be.pairwise(coef, z, g_all.contiguous(), v_all.contiguous(), out=into)
-            if self.world > 1:
-                cgv = torch.stack([pw['cg'], pw['cv']])
-                self._all_reduce(cgv)                       # both column terms in one collective
-                cg, cv = cgv[0], cgv[1]
-            else:
-                cg, cv = pw['cg'], pw['cv']
-            self.ws.view('cg', Bl, dl).copy_(cg[lo:hi])
-            self.ws.view('cv', Bl, dl).copy_(cv[lo:hi])
+            pw = be.pairwise(coef, z, g_all, v_all, out=into)
+            cg, cv = self._reduce_cols(pw['cg'], pw['cv'], lo, hi, global_batch)
+            self.ws.view('cg', Bl, dl).copy_(cg)
+            self.ws.view('cv', Bl, dl).copy_(cv)
             loss, grads = be.backward(sh, coef, params, x, u, eps, self.ws, gl_out=self._gl)
         # ONE collective per step: the loss rides behind the gradient (the exchange is latency-bound, 80-190 KB)
         self._all_reduce(self._gl)

@@ -66,6 +66,7 @@ def _worker(rank, world, port, B, steps, coef, out):
 @pytest.mark.parametrize("B,coef", [
     (12, dict(pairwise=False)),                                              # iVAE plain ELBO (nets.py:475)
     (13, dict(a=100., b=1., c=0., d=10., N=4000., pairwise=True)),           # cleanIVAE weights of configs/ivae.yaml, ragged
+    (12, dict(a=100., b=1., c=0., d=10., N=4000., pairwise=True)),           # equal shards: one all-gather of (g, v), reduce-scatter of (cg, cv)
     (13, dict(a=1000., b=1., c=15., d=1., N=4000., pairwise=True)),          # beta-TCVAE weights of configs/btcvae.yaml
 ])
 def test_two_ranks_reproduce_single_rank(B, coef):

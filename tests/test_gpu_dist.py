@@ -48,7 +48,8 @@ def _worker(rank, world, port, name, out, backend="gloo"):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(d)
         co = c.coef(0)
         class HostStagedELBO(DataParallelELBO):
-            """Test double: gloo cannot take ROCm tensors, so the two collectives go through host memory."""
+            """Test double: gloo cannot take ROCm tensors, so the collectives go through host memory (the reduce-scatter of
+            the column terms is an all-reduce + own chunk on gloo: DataParallelELBO._reduce_scatter_into)."""
 
             def _all_reduce(self, t_):
                 h = t_.cpu()
@@ -58,6 +59,11 @@ def _worker(rank, world, port, name, out, backend="gloo"):
 
             def _all_gather_rows(self, t_, global_batch):
                 return super()._all_gather_rows(t_.cpu(), global_batch).to(t_.device)
+
+            def _all_gather_into(self, out_, t_):
+                h = torch.empty(out_.shape, dtype=out_.dtype)
+                dist.all_gather_into_tensor(h, t_.cpu(), group=self.group)
+                out_.copy_(h)
 
         dp = (DataParallelELBO if rccl else HostStagedELBO)(shape, s.decoder_var)
         loss, z, grads = dp.fwd_bwd(t(_flat(c.params, s.param_names())), t(x[lo:hi]), t(u[lo:hi]) if s.aux_dim else None,
