@@ -71,10 +71,12 @@ int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params
     return e == hipSuccess ? IVAE_OK : hip_fail(e, "ivae_forward");
 }
 
+// the pairwise kernels form element indices (row * latent_dim, slice geometry) in 32-bit integers
+#define IVAE_PAIR_MAX_N (1 << 24)
 int ivae_pairwise_workspace_bytes(int32_t n_rows, int32_t n_cols, int32_t latent_dim, size_t* out) {
     if (!out) return IVAE_E_NULLPTR;
     if (n_rows <= 0 || n_cols <= 0 || latent_dim <= 0) return IVAE_E_BADDIMS;
-    if (latent_dim > 64) return IVAE_E_TOOLARGE;
+    if (latent_dim > 64 || n_rows > IVAE_PAIR_MAX_N || n_cols > IVAE_PAIR_MAX_N) return IVAE_E_TOOLARGE;
     *out = pairwise_ws_floats(n_rows, n_cols, latent_dim) * sizeof(float);
     return IVAE_OK;
 }
@@ -83,7 +85,7 @@ int ivae_pairwise(int32_t n_rows, int32_t n_cols, int32_t latent_dim, const Ivae
                   const float* g_cols, const float* v_cols, float* lq, float* lqi, float* lse_s, float* lse_k,
                   float* rz, float* cg, float* cv, void* workspace, size_t workspace_bytes, void* stream) {
     if (n_rows <= 0 || n_cols <= 0 || latent_dim <= 0) return IVAE_E_BADDIMS;
-    if (latent_dim > 64) return IVAE_E_TOOLARGE;
+    if (latent_dim > 64 || n_rows > IVAE_PAIR_MAX_N || n_cols > IVAE_PAIR_MAX_N) return IVAE_E_TOOLARGE;
     if (!coef || !z || !g_cols || !v_cols || !lq || !lqi || !lse_s || !lse_k || !rz || !cg || !cv) return IVAE_E_NULLPTR;
     if (!(coef->dataset_size > 0.f) || coef->global_batch <= 0) return IVAE_E_BADDIMS;
     const size_t need = pairwise_ws_floats(n_rows, n_cols, latent_dim) * sizeof(float);

@@ -219,5 +219,7 @@ static inline int ivae_make_layout(const IvaeDims* d, bool with_pair, Layout* Lo
     L.ws_pair = take(with_pair ? (int64_t)ivae_pair_ws_floats(L.B, L.B, L.dl) : 0);
     wso = (wso + 63) & ~(int64_t)63;
     L.ws.per_model = wso;
+    // callers form per_model * n_models * sizeof(float) in size_t: refuse what no memory holds before that can wrap
+    if (wso > ((int64_t)1 << 44) / L.n_models) return IVAE_E_TOOLARGE;
     return IVAE_OK;
 }
