@@ -63,28 +63,32 @@ def _worker(rank, world, port, B, steps, coef, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B,coef", [
-    (12, dict(pairwise=False)),                                              # iVAE plain ELBO (nets.py:475)
-    (13, dict(a=100., b=1., c=0., d=10., N=4000., pairwise=True)),           # cleanIVAE weights of configs/ivae.yaml, ragged
-    (12, dict(a=100., b=1., c=0., d=10., N=4000., pairwise=True)),           # equal shards: one all-gather of (g, v), reduce-scatter of (cg, cv)
-    (13, dict(a=1000., b=1., c=15., d=1., N=4000., pairwise=True)),          # beta-TCVAE weights of configs/btcvae.yaml
+@pytest.mark.parametrize("world,B,coef", [
+    (2, 12, dict(pairwise=False)),                                           # iVAE plain ELBO (nets.py:475)
+    (2, 13, dict(a=100., b=1., c=0., d=10., N=4000., pairwise=True)),        # cleanIVAE weights of configs/ivae.yaml, ragged
+    (2, 12, dict(a=100., b=1., c=0., d=10., N=4000., pairwise=True)),        # equal shards: one all-gather of (g, v), reduce-scatter of (cg, cv)
+    (2, 13, dict(a=1000., b=1., c=15., d=1., N=4000., pairwise=True)),       # beta-TCVAE weights of configs/btcvae.yaml
+    (4, 12, dict(a=1000., b=1., c=15., d=1., N=4000., pairwise=True)),       # four ranks, equal shards: the ranks' row blocks must land in rank order
+    (3, 13, dict(a=100., b=1., c=.5, d=10., N=4000., pairwise=True)),        # three ranks, shards of 5 / 4 / 4 rows (padded path)
+    (4, 14, dict(pairwise=False)),                                           # four ranks, plain ELBO, shards of 4 / 4 / 3 / 3 rows
 ])
-def test_two_ranks_reproduce_single_rank(B, coef):
+def test_ranks_reproduce_single_rank(world, B, coef):
     steps = 3
     ref_losses, ref_params, ref_v = _train(0, 1, B, steps, coef)
     ctx = mp.get_context("spawn")
     out = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, steps, coef, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, steps, coef, out)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([out.get() for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, l0, p0, v0, g0), (_, l1, p1, v1, g1) = res
+    (_, l0, p0, v0, g0), (_, l1, p1, v1, g1) = res[0], res[-1]
     # replicas stay bit-identical without any parameter broadcast
-    assert np.array_equal(p0, p1) and np.array_equal(v0, v1) and np.array_equal(l0, l1)
+    for (_, l, p, v, g) in res[1:]:
+        assert np.array_equal(p0, p) and np.array_equal(v0, v) and np.array_equal(l0, l)
     # and equal the single-rank full-batch run (fp32 interface, different summation split: 1e-5)
     assert np.allclose(l0, ref_losses, rtol=1e-5, atol=0)
     assert np.abs(p0 - ref_params).max() < 1e-5 * max(1., np.abs(ref_params).max())
