@@ -607,7 +607,9 @@ __global__ __launch_bounds__(256) void k_pair_rows_wide(int n_rows, int n_cols, 
             if (k < d) {
                 const float gg = g[(size_t)j * d + k], vv = v[(size_t)j * d + k];
                 const float dq = zi[k] - gg;
-                const float t = -0.5f * (LOG2PI + logf(vv) + dq * dq / vv);
+                // (the form the gradient walks below and k_pair_cols_wide use: a weight exp(T - lse) is then formed from the
+                // very T that went into the lse -- with dq * dq / vv here a single far column weighed 1.017 instead of 1)
+                const float t = -0.5f * (LOG2PI + logf(vv) + dq * (dq / vv));
                 S += t;
                 lse_push(mk[k], sk[k], t);
             }
