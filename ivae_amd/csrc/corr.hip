@@ -19,6 +19,11 @@ size_t corr_ws_bytes(int64_t n, int d) {
     return sizeof(double) * ((size_t)2 * d + (size_t)CORR_BLOCKS * 2 * d + (size_t)CORR_BLOCKS * ((size_t)d * d + 2 * d));
 }
 
+// np.corrcoef clips to [-1, 1] with np.clip, which PROPAGATES nan: a column of zero variance gives 0 / 0 there and the
+// block is not finite -- the reference's Hungarian step then raises and the runner scores the batch 0
+// (runners/ivae.py:85-88).  fmin / fmax would turn that nan into -1, i.e. into a perfect |correlation|.
+__device__ __forceinline__ double clip_unit(double c) { return c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c); }
+
 #define CORR_SUM_THREADS 1024
 __global__ __launch_bounds__(CORR_SUM_THREADS) void k_corr_sums(const float* __restrict__ x, const float* __restrict__ y,
                                                                 int64_t n, int d, double* __restrict__ psum) {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(1024) void k_corr_final(const double* __restrict__ 
         const int o = o0 + threadIdx.x, a = o / d, b = o - a * d;
         double c = cross[threadIdx.x] / sqrt(autos[a]);
         c = c / sqrt(autos[d + b]);
-        cc[o] = fmin(1.0, fmax(-1.0, c));     // np.corrcoef clips to [-1, 1]
+        cc[o] = clip_unit(c);
     }
 }
 
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void k_corr_batched(const float* __restrict__ 
         const int a = o / d, b = o - a * d;
         double c = mom[o] / sqrt(mom[d * d + a]);
         c = c / sqrt(mom[d * d + d + b]);
-        cc[(size_t)blockIdx.x * d * d + o] = fmin(1.0, fmax(-1.0, c));
+        cc[(size_t)blockIdx.x * d * d + o] = clip_unit(c);
     }
 }
 

@@ -429,6 +429,38 @@ def test_corr_batched_matches_numpy_corrcoef(nb, n, d):
         assert np.abs(cc[b] - one).max() < 1e-12
 
 
+@pytest.mark.parametrize("n,d", [(65, 5), (64, 15), (40000, 16)])
+def test_corr_of_a_constant_column_is_nan_like_numpy(n, d):
+    """A column of zero variance: np.corrcoef divides 0 by 0 and np.clip keeps the nan (metrics/mcc.py:328), the
+    reference's Hungarian step then raises and its runner scores the batch 0 (runners/ivae.py:85-88).  The kernels must
+    hand back the same nan pattern -- a clip by fmin / fmax would turn it into -1, a perfect |correlation| -- in all three
+    entry points; the host side then scores such a block 0 (runners._assignment_scores)."""
+    from ivae_amd.runners import _assignment_scores
+    rng = np.random.RandomState(d)
+    x = rng.randn(n, d).astype(np.float32)
+    y = (x @ rng.randn(d, d) + rng.randn(n, d)).astype(np.float32)
+    x[:, 0] = 3.25
+    y[:, d - 1] = -7.5
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = np.corrcoef(x.astype(np.float64), y.astype(np.float64), rowvar=False)[:d, d:]
+    assert np.isnan(ref[0]).all() and np.isnan(ref[:, d - 1]).all()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    import ctypes as C
+    from ivae_amd import _lib
+    xs, ys = t(x), t(y)
+    cs = torch.empty(d, d, dtype=torch.float64, device=dev())
+    assert _lib.lib().ivae_corr_static(C.c_void_p(xs.data_ptr()), C.c_void_p(ys.data_ptr()), n, d, C.c_void_p(cs.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream(dev()).cuda_stream)) == 0
+    outs = [ops.corr(xs, ys).cpu().numpy(), cs.cpu().numpy()]
+    if n <= 300:
+        outs.append(ops.corr_batched(t(x[None]), t(y[None])).cpu().numpy()[0])
+    for got in outs:
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.abs(got[ok] - ref[ok]).max() < 1e-12
+        assert _assignment_scores([np.abs(got)]) == [0.]
+
+
 @pytest.mark.parametrize("wgrad_rows", [16, 32, 64, 128, 256])
 @pytest.mark.parametrize("name", ["ivae_plain_b70", "cleanvae_btcvae_b200", "ivae_plain_cfg4s"])
 def test_every_wgrad_row_tiling_matches_reference_fixture(name, wgrad_rows, monkeypatch):
