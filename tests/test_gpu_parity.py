@@ -127,7 +127,8 @@ def test_module_training_trajectory(name):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in c.params.items()})
     model = model.to(d)
     opt = ivae_amd.FusedAdam(model.parameters(), lr=1e-2)
-    anneal_it = {"ivae_anneal_tiny": 300, "ivae_anneal_cfg2": 1, "ivae_anneal_switch": 623}.get(name)
+    # (fixtures of round 3 carry their annealing iteration; the first ones are listed here)
+    anneal_it = c.meta.get("anneal_it", {"ivae_anneal_tiny": 300, "ivae_anneal_cfg2": 1, "ivae_anneal_switch": 623}.get(name))
     for k in range(4):
         if k == 3:
             for grp in opt.param_groups:
@@ -137,7 +138,7 @@ def test_module_training_trajectory(name):
         opt.zero_grad()
         if c.family == "iVAE":
             if anneal_it is not None:
-                model.anneal(c.meta["N"], 1000, anneal_it + k)
+                model.anneal(c.meta["N"], c.meta.get("max_iter", 1000), anneal_it + k)
             elbo, z = model.elbo(x, u, eps=eps)
             loss = elbo.mul(-1)
         elif c.family == "VAE":

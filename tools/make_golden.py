@@ -58,7 +58,7 @@ def make_case(name, family, dims, B, coef=None, anneal_it=None, max_iter=1000, N
     out = {}
     meta = dict(name=name, family=family, latent_dim=d_lat, data_dim=d_data, aux_dim=M if has_u else 0,
                 hidden_dim=H, n_layers=n_layers, activation=act, slope=slope, batch=B, N=N,
-                decoder_var=float(model.decoder_var.item()), torch=torch.__version__)
+                decoder_var=float(model.decoder_var.item()), torch=torch.__version__, anneal_it=anneal_it, max_iter=max_iter)
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
 
     def one_step(k):
@@ -636,8 +636,31 @@ def merge_full_traces():
     print("merged", len(index), "runs")
 
 
+def make_random_cases(n=24):
+    """More reference-made fixtures at random small shapes (round 3): every model class, 1-4 layers, every activation,
+    one-hot and dense u, ragged batches, random loss weights for the decomposed ELBO, annealed iVAE at random iterations
+    (both sides of the switch to the plain ELBO) -- the tests pick up every *.npz of tests/golden."""
+    r = np.random.RandomState(2024)
+    for i in range(n):
+        family = ["iVAE", "VAE", "cleanIVAE", "cleanVAE"][i % 4]
+        dl, dd = int(r.randint(2, 13)), int(r.randint(2, 13))
+        M = int(r.randint(2, 21)) if family in ("iVAE", "cleanIVAE") else 0
+        kw = dict(B=int(r.randint(3, 91)), H=int(r.randint(5, 41)), n_layers=int(r.randint(1, 5)),
+                  act=str(r.choice(["lrelu", "xtanh", "sigmoid", "none"])), slope=float(r.choice([.1, .2])),
+                  seed=100 + i, N=int(r.choice([4000, 40000, 1000000])), store_steps=False)
+        if family in ("iVAE", "cleanIVAE"):
+            kw["dense_u"] = bool(r.randint(2))
+        if family.startswith("clean"):
+            kw["coef"] = tuple(float(t) for t in np.round(r.uniform(.2, 20., 4), 3))
+        elif family == "iVAE" and r.randint(2):
+            kw["anneal_it"] = int(r.choice([0, 5, 300, 620, 700]))
+        make_case("rnd_%02d_%s" % (i, family.lower()), family, (dl, dd, M), **kw)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "random_cases":
+        return make_random_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "runner_traces":
         return make_runner_traces()
     if len(sys.argv) > 1 and sys.argv[1] == "datasets":
