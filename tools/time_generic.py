@@ -22,6 +22,7 @@ CFG = {
     "h200L": (ops.ModelShape(10, 10, 40, 200, 3, "lrelu", .1), 16384, dict(pairwise=False), 1000000),   # wrapper shapes, chip-filling batch
     "d20": (ops.ModelShape(20, 20, 40, 50, 3, "lrelu", .1), 64, dict(pairwise=False), 40000),          # sweep shapes (packs)
     "d40": (ops.ModelShape(40, 40, 40, 50, 3, "lrelu", .1), 64, dict(pairwise=False), 40000),
+    "cfg3m8": (ops.ModelShape(20, 20, 8, 50, 3, "lrelu", .1), 4096, dict(pairwise=False), 1000000),      # configs[3] with 8 segments: what its one-hot u costs
     "cfg3p": (ops.ModelShape(20, 20, 200, 50, 3, "lrelu", .1), 4096, dict(a=1., b=1., c=2., d=1., pairwise=True), 1000000),
 }
 
