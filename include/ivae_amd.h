@@ -88,7 +88,8 @@ int ivae_param_count(const IvaeDims* dims, int64_t* out);
 /* Bytes of caller-provided scratch the calls below need for `dims` (all models) when they are given a coef with this
  * `pairwise` flag.  pairwise = 0: linear in the batch.  pairwise != 0: plus the pairwise kernels' scratch for a
  * (batch, batch, latent_dim) problem, which grows roughly as batch^2 * latent_dim / 341 -- so query with 0 for plain
- * calls (a full-dataset ivae_forward).  A workspace sized with pairwise != 0 also serves pairwise = 0 calls. */
+ * calls (a full-dataset ivae_forward).  A workspace sized with pairwise != 0 also serves pairwise = 0 calls.
+ * Layouts beyond 2^44 floats over all models return IVAE_E_TOOLARGE (the byte count is formed in size_t). */
 int ivae_workspace_bytes(const IvaeDims* dims, int32_t pairwise, size_t* out);
 
 /* Row-tensor offsets for the same (dims, pairwise); only per_model depends on `pairwise`. */
@@ -122,7 +123,8 @@ int ivae_forward(const IvaeDims* dims, const IvaeCoef* coef, const float* params
  * Columns j: g_cols, v_cols (n_cols, d) of the GLOBAL batch.  Writes lq, lqi, rz (n_rows,*)
  * and cg, cv (n_cols, d) (column sums over this shard's rows).  Single model only.
  * workspace: at least ivae_pairwise_workspace_bytes(n_rows, n_cols, latent_dim) bytes of caller-owned
- * scratch (per-slice log-sum-exp statistics and gradient partial sums, merged in a fixed order). */
+ * scratch (per-slice log-sum-exp statistics and gradient partial sums, merged in a fixed order).
+ * Limits: latent_dim <= 64; n_rows, n_cols <= 2^24 (element indices are 32-bit): IVAE_E_TOOLARGE beyond. */
 int ivae_pairwise_workspace_bytes(int32_t n_rows, int32_t n_cols, int32_t latent_dim, size_t* out);
 int ivae_pairwise(int32_t n_rows, int32_t n_cols, int32_t latent_dim, const IvaeCoef* coef,
                   const float* z, const float* g_cols, const float* v_cols,
@@ -207,7 +209,9 @@ int ivae_adam_step(float* params, float* exp_avg, float* exp_avg_sq, const float
  * Replaces np.corrcoef(x, y, rowvar=False)[:d, d:] of metrics/mcc.py:328 (float64
  * arithmetic on fp32 inputs).  x, y: (n, d) fp32; cc_out: (d, d) float64 on device.
  * workspace: at least ivae_corr_workspace_bytes(n, d) bytes.  The Hungarian assignment
- * (metrics/mcc.py:334) stays on the host. */
+ * (metrics/mcc.py:334) stays on the host.  A column of zero variance gives nan in its row / column of cc_out, as
+ * np.corrcoef does (0 / 0; its clip to [-1, 1] keeps nan): the reference's runner scores such a batch 0
+ * (runners/ivae.py:85-88). */
 int ivae_corr_workspace_bytes(int64_t n, int32_t d, size_t* out);
 int ivae_corr(const float* x, const float* y, int64_t n, int32_t d, double* cc_out,
               void* workspace, size_t workspace_bytes, void* stream);
