@@ -228,6 +228,10 @@ class _FusedModel(nn.Module):
         return loss[:, 0], z
 
     def _loss(self, x, u, a, b, c, d, N, pairwise, eps=None):
+        if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (x, u)):
+            # the reference's autograd would hand back dLoss/dx; the kernels form parameter gradients only -- say so
+            # instead of leaving x.grad silently empty
+            raise NotImplementedError('the fused path does not differentiate with respect to its inputs (x, u): detach them')
         eps = self._eps(x, eps)
         coef = ops.make_coef(a, b, c, d, N, self._decoder_var_f, pairwise, x.shape[0])
         return _ElboFn.apply(self, coef, x, u, eps, *self.parameters())

@@ -178,6 +178,9 @@ def test_no_cpu_fallback():
     m = ivae_amd.iVAE(3, 3, 4, hidden_dim=8)
     with pytest.raises(RuntimeError):
         m.elbo(torch.randn(5, 3), torch.randn(5, 4))
+    # the reference's autograd would return dLoss/dx; the fused path forms parameter gradients only and says so
+    with pytest.raises(NotImplementedError):
+        m.elbo(torch.randn(5, 3, requires_grad=True), torch.randn(5, 4))
     with pytest.raises(NotImplementedError):
         class Lap:
             name = 'laplace'
