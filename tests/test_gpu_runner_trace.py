@@ -1,7 +1,8 @@
 """Family-A loop parity: `ivae_amd.runners.runner` against runs of the REFERENCE's own
 `runners/ivae.py::runner` recorded by tools/make_golden.py (`runner_traces`: ivae.yaml and btcvae.yaml, 2 epochs, seeds
 0-1; ivae.yaml with anneal on, 3 epochs, which crosses the weight switch of runners/ivae.py:51-60 and makes
-ReduceLROnPlateau(factor .1, patience 0) cut the learning rate twice).
+ReduceLROnPlateau(factor .1, patience 0) cut the learning rate twice; vae.yaml and bvae.yaml, 2 epochs, seed 0 -- every
+yaml file the reference ships for this loop is replayed).
 
 The replay feeds the recorded batch order (DataLoader(shuffle=True, drop_last=True), :25) and re-draws the recorded
 noise from its seeds (CPU generator, identical on every machine), so everything else is the loop under test: model

@@ -357,6 +357,8 @@ RUNNER_CASES = [
     ("ivae", "ivae.yaml", {}, (0, 1), 2),
     ("btcvae", "btcvae.yaml", {}, (0, 1), 2),
     ("ivae_anneal", "ivae.yaml", {"anneal": True}, (0,), 3),     # epoch > epochs/1.6 switches the weights at epoch 2
+    ("vae", "vae.yaml", {}, (0,), 2),                            # the other two yaml files of the reference (cleanVAE with
+    ("bvae", "bvae.yaml", {}, (0,), 2),                          # the VAE / beta-VAE loss weights): every config is replayed
 ]
 
 
@@ -369,7 +371,7 @@ def eval_seed(seed):
     return 777 + seed
 
 
-def make_runner_traces():
+def make_runner_traces(only=()):
     """Run `runners.ivae.runner(args, config)` of the reference (runners/ivae.py:13-128) exactly as main.py:47-62 does --
     np.random.seed / torch.manual_seed(seed), yaml -> Namespace -- on CPU, with recording shims only:
       * the dataset's __getitem__ logs the row order the DataLoader(shuffle=True, drop_last=True) asked for;
@@ -429,9 +431,16 @@ def make_runner_traces():
     R.SyntheticDataset, R.cleanIVAE, R.cleanVAE = RecDataset, recording(R.cleanIVAE), recording(R.cleanVAE)
     torch.optim.lr_scheduler.ReduceLROnPlateau = RecPlateau
     out, index = {}, []
+    cases = RUNNER_CASES
+    if only:            # add the named cases to the existing file, leave its other runs as they are
+        old = np.load(os.path.join(OUT, "trace_runner.npz"))
+        out = {k: old[k] for k in old.files if k != "index"}
+        index = [r for r in json.loads(str(old["index"])) if r["name"] not in only]
+        out = {k: v for k, v in out.items() if k.split(".")[0] not in only}
+        cases = [c for c in RUNNER_CASES if c[0] in only]
     try:
         with tempfile.TemporaryDirectory() as tmp:
-            for name, yml, over, seeds, epochs in RUNNER_CASES:
+            for name, yml, over, seeds, epochs in cases:
                 with open(os.path.join(REF, "configs", yml)) as f:
                     cfg = yaml.safe_load(f)
                 cfg.update(over)
@@ -661,8 +670,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "random_cases":
         return make_random_cases()
-    if len(sys.argv) > 1 and sys.argv[1] == "runner_traces":
-        return make_runner_traces()
+    if len(sys.argv) > 1 and sys.argv[1] == "runner_traces":          # runner_traces [case names to (re)make and merge]
+        return make_runner_traces(tuple(sys.argv[2:]))
     if len(sys.argv) > 1 and sys.argv[1] == "datasets":
         return make_datasets()
     if len(sys.argv) > 1 and sys.argv[1] == "traces":
