@@ -219,6 +219,9 @@ def runner(args, config, *, replay=None, trace=None, init_seeds=False, init_pert
 
 
 # ------------------------------------------------------------------------------------------------ family B
+_PLAIN = (1., 1., 1., 1., 1., False)          # loss weights (a, b, c, d, N, pairwise) of the plain ELBO
+
+
 class _FusedEpochs:
     """Epoch driver for models the fused kernel covers: full batches go through `ivae_train_steps` (the model's
     own arena is the kernel's parameter buffer), a ragged final batch through the generic kernels with the same
@@ -237,16 +240,19 @@ class _FusedEpochs:
         self.group = {'lr': lr, 'betas': (0.9, 0.999), 'eps': 1e-8}
         self.param_groups = [self.group]           # what ReduceLROnPlateau mutates
 
-    def full_batches(self, X, U, idx):
-        """idx: (k, 64) int32 rows.  -> (loss (k,), z (k, 64, d)) on the device."""
+    def full_batches(self, X, U, idx, eps=None):
+        """idx: (k, 64) int32 rows [eps (k, 64, d): the steps' noise instead of the kernel's own generator].
+        -> (loss (k,), z (k, 64, d)) on the device."""
         loss, z = ops.train_steps(self.shape, self.coef, self.params.view(1, -1), self.m.view(1, -1), self.v.view(1, -1),
                                   X.unsqueeze(0), None if U is None else U.unsqueeze(0), idx.unsqueeze(0), self.t,
-                                  self.group['lr'], seed=self.seed, want_z_steps=True)
+                                  self.group['lr'], eps=None if eps is None else eps.unsqueeze(0).contiguous(),
+                                  seed=self.seed, want_z_steps=True)
         self.t += idx.shape[0]
         return loss[0], z[0]
 
-    def ragged_batch(self, x, u):
-        eps = torch.randn(x.shape[0], self.shape.latent_dim, device=x.device)
+    def ragged_batch(self, x, u, eps=None):
+        if eps is None:
+            eps = torch.randn(x.shape[0], self.shape.latent_dim, device=x.device)
         coef = ops.make_coef(decoder_var=self.model._decoder_var_f, global_batch=x.shape[0])
         loss, z, grads = ops.elbo_fwd_bwd(self.shape, coef, self.params, x, u, eps, self.ws)
         self.t += 1
@@ -266,7 +272,12 @@ class _FusedEpochs:
 
 
 def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, log_folder, ckpt_folder, scheduler_tol,
-                    seed, with_u):
+                    seed, with_u, replay=None, trace=None):
+    """The loop of models/wrappers.py:54-95 / :137-176.  Test hooks, as in `runner` (tests/test_gpu_wrapper_trace.py replays
+    runs recorded from the reference's wrappers draw for draw): `replay.order(epoch)` the epoch's N rows in DataLoader
+    order, `replay.eps(it, rows)` the noise of iteration `it` (1-based), `replay.eval_eps()` that of the final full-data
+    forward, `replay.init_state()` (optional) initial parameters to start from instead of the drawn ones; `trace` (a dict) receives per-iteration losses and loss weights, the learning rate after each epoch and
+    the iterations that got a checkpoint."""
     N = len(dset)
     X = dset.x.to(device)
     U = dset.u.to(device) if with_u else None
@@ -276,6 +287,15 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
     gen = torch.Generator(device=device)
     gen.manual_seed(int(torch.initial_seed()) % (2 ** 63))
     fused = (not anneal and batch_size == 64 and ops.train_steps_supported(model._shape, 64))
+    if trace is not None:
+        trace['init'] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    if replay is not None and hasattr(replay, 'init_state'):
+        # a run recorded on a CPU: iVAE redraws its weights with xavier_uniform_ AFTER the move to the device (nets.py:432,
+        # as the reference does), i.e. from the device's generator, which no CPU run can reproduce
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                if k in replay.init_state():
+                    v.copy_(replay.init_state()[k])
     if fused:
         drv = _FusedEpochs(model, lr, seed)
         # ReduceLROnPlateau wants an Optimizer: a placeholder holds the learning rate the kernel is launched with
@@ -303,6 +323,8 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
         """wrappers.py:78-80: a checkpoint whenever `it` is a multiple of max_iter / 5, holding the state AT that iteration."""
         if ckpt_folder is not None and ckpt_every > 0 and it % ckpt_every == 0:
             opt = drv.as_optimizer() if fused else optimizer
+            if trace is not None:
+                trace.setdefault('ckpt_its', []).append(it)
             checkpoint(ckpt_folder, exp_id, it, model, opt, last('elbo'), last('perf'))
 
     def segments(it, n):
@@ -324,7 +346,23 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
     model.train()
     while it < max_iter:
         epoch = it // n_batches + 1
-        batches = _epoch_batches(N, batch_size, False, device, gen)
+        if replay is None:
+            batches = _epoch_batches(N, batch_size, False, device, gen)
+        else:
+            order = replay.order(epoch).to(device)
+            batches = [order[i:i + batch_size] for i in range(0, N, batch_size)]
+
+        it0 = it
+
+        def noise(a, b):         # batches a .. b - 1 of this epoch of the replayed run (None: the device generators draw)
+            if replay is None:
+                return None
+            return torch.stack([replay.eps(it0 + 1 + k, batches[k].numel()) for k in range(a, b)]).to(device)
+
+        def note(losses, coefs):
+            if trace is not None:
+                trace.setdefault('step_loss', []).append(losses.detach().reshape(-1).cpu())
+                trace.setdefault('step_coef', []).extend(coefs)
         cc = torch.empty(len(batches), d, d, dtype=torch.float64, device=device) if S is not None else None
         n_full = N // batch_size
         if fused:
@@ -333,15 +371,18 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                 idx = torch.stack(batches[:n_full]).to(torch.int32)
                 zs = torch.empty(n_full, batch_size, d, device=device)
                 for a0, b0 in segments(it, n_full):
-                    loss, zs[a0:b0] = drv.full_batches(X, U, idx[a0:b0].contiguous())
+                    loss, zs[a0:b0] = drv.full_batches(X, U, idx[a0:b0].contiguous(), eps=noise(a0, b0))
                     logger.update('elbo', loss.sum(), weight=b0 - a0)
+                    note(loss, [_PLAIN] * (b0 - a0))
                     it += b0 - a0
                     maybe_checkpoint(it)
                 if cc is not None:              # the per-step batch scores (wrappers.py:75), one launch per epoch
                     cc[:n_full] = ops.corr_batched(zs, Z[idx.long().view(-1)].view(n_full, batch_size, d))
             for i in range(n_full, len(batches)):
-                l1, z1 = drv.ragged_batch(X[batches[i]], None if U is None else U[batches[i]])
+                e1 = noise(i, i + 1)
+                l1, z1 = drv.ragged_batch(X[batches[i]], None if U is None else U[batches[i]], None if e1 is None else e1[0])
                 logger.update('elbo', l1)
+                note(l1, [_PLAIN])
                 if cc is not None:
                     cc[i] = corr_matrix_gpu(z1, Z[batches[i]])
                 it += 1
@@ -364,12 +405,16 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                             else:
                                 coefs.append((1., 1., 1., 1., 1., False))
                     losses, _ = model.direct_steps(optimizer, X[idx[a0:b0]], U[idx[a0:b0]] if with_u else None, 1., 1., 1.,
-                                                   1., 1., False, z_out=None if Ze is None else Ze[a0:b0], coefs=coefs)
+                                                   1., 1., False, eps=noise(a0, b0),
+                                                   z_out=None if Ze is None else Ze[a0:b0], coefs=coefs)
                     logger.update('elbo', losses.sum(), weight=b0 - a0)
+                    note(losses, coefs or [_PLAIN] * (b0 - a0))
                     it += b0 - a0
                     maybe_checkpoint(it)
             for i in range(n_full, len(batches)):        # the ragged final batch (wrappers.py:28 has no drop_last)
                 bidx = batches[i]
+                e1 = noise(i, i + 1)
+                e1 = None if e1 is None else e1[0]
                 it += 1
                 if anneal:
                     model.anneal(N, max_iter, it)
@@ -377,10 +422,12 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                 # coefficients are what model.elbo would pass (nets.py:457-475)
                 if with_u and model.anneal_params:
                     a_, b_, c_, d_, N_ = model._training_hyperparams
-                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx], a_, b_, c_, d_, N_, True)
+                    loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx], a_, b_, c_, d_, N_, True, eps=e1)
+                    note(loss, [(a_, b_, c_, d_, N_, True)])
                 else:
                     loss, z_est = model.direct_step(optimizer, X[bidx], U[bidx] if with_u else None, 1., 1., 1., 1., 1.,
-                                                    False)
+                                                    False, eps=e1)
+                    note(loss, [_PLAIN])
                 logger.update('elbo', loss)
                 if cc is not None:
                     cc[i] = corr_matrix_gpu(z_est, Z[bidx])
@@ -392,6 +439,8 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                 logger.update('perf', score)
         logger.log()
         scheduler.step(logger.get_last('elbo'))
+        if trace is not None:
+            trace.setdefault('lr', []).append(scheduler.optimizer.param_groups[0]['lr'])
         if S is not None:
             print('epoch {}/{} \tloss: {}\tperf: {}'.format(epoch, max_epochs, logger.get_last('elbo'),
                                                             logger.get_last('perf')))
@@ -399,15 +448,16 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
             print('epoch {}/{} \tloss: {}'.format(epoch, max_epochs, logger.get_last('elbo')))
 
     with torch.no_grad():
-        decoder_params, encoder_params, z, prior_params = model(X, U) if with_u else model(X)
+        ev = None if replay is None else replay.eval_eps().to(device)
+        decoder_params, encoder_params, z, prior_params = model(X, U, eps=ev) if with_u else model(X, eps=ev)
     params = {'decoder': decoder_params, 'encoder': encoder_params, 'prior': prior_params}
     return z, model, params, logger
 
 
 def IVAE_wrapper(X, U, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers=3, hidden_dim=200, lr=1e-2, cuda=True,
                  activation='lrelu', slope=.1, discrete=False, inference_dim=None,
-                 anneal=False, log_folder=None, ckpt_folder=None, scheduler_tol=3):
-    """models/wrappers.py:14-95.  Returns (z, model, params, logger)."""
+                 anneal=False, log_folder=None, ckpt_folder=None, scheduler_tol=3, *, replay=None, trace=None):
+    """models/wrappers.py:14-95.  Returns (z, model, params, logger).  (`replay`, `trace`: test hooks, see _train_family_b.)"""
     if discrete:
         raise NotImplementedError('DiscreteIVAE is outside the fused hot path (SURVEY.md §2 row 15)')
     if not cuda:
@@ -424,12 +474,12 @@ def IVAE_wrapper(X, U, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers
     model = iVAE(latent_dim, data_dim, aux_dim, activation=activation, device=device, n_layers=n_layers,
                  hidden_dim=hidden_dim, slope=slope, anneal=anneal)
     return _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, log_folder, ckpt_folder,
-                           scheduler_tol, seed, with_u=True)
+                           scheduler_tol, seed, with_u=True, replay=replay, trace=trace)
 
 
 def VAE_wrapper(X, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers=3, hidden_dim=200, lr=1e-2, cuda=True,
                 activation='lrelu', slope=.1, discrete=False, inference_dim=None,
-                log_folder=None, ckpt_folder=None, scheduler_tol=3):
+                log_folder=None, ckpt_folder=None, scheduler_tol=3, *, replay=None, trace=None):
     """models/wrappers.py:98-176."""
     if discrete:
         raise NotImplementedError('DiscreteVAE is outside the fused hot path (SURVEY.md §2 row 15)')
@@ -447,4 +497,4 @@ def VAE_wrapper(X, S=None, batch_size=256, max_iter=7e4, seed=None, n_layers=3, 
     model = VAE(latent_dim, data_dim, activation=activation, device=device, n_layers=n_layers, hidden_dim=hidden_dim,
                 slope=slope)
     return _train_family_b(model, dset, S, batch_size, max_iter, lr, device, False, log_folder, ckpt_folder,
-                           scheduler_tol, seed, with_u=False)
+                           scheduler_tol, seed, with_u=False, replay=replay, trace=trace)

@@ -645,6 +645,115 @@ def merge_full_traces():
     print("merged", len(index), "runs")
 
 
+# ---- family-B loop traces: the reference's own models/wrappers.py, run unmodified ---------------------------------------
+WRAPPER_CASES = [
+    # key, wrapper, data kwargs (ivae_amd.data.generate_data == data/data.py, bit for bit), wrapper kwargs
+    # (the reference prints logger.get_last() at a checkpoint, which raises before the first epoch has been logged:
+    #  every case keeps its first checkpoint, at int(max_iter / 5), beyond the first epoch)
+    ("ivae_fused", "IVAE", dict(n_per_seg=25, n_seg=20, d_sources=10, n_layers=3, seed=3, activation="lrelu"),
+     dict(batch_size=64, max_iter=50, seed=5, hidden_dim=50, lr=1e-2)),                 # the fused kernel's shape; 7 full batches + 52 rows
+    ("ivae_anneal", "IVAE", dict(n_per_seg=25, n_seg=20, d_sources=10, n_layers=3, seed=3, activation="lrelu"),
+     dict(batch_size=64, max_iter=50, seed=6, hidden_dim=50, lr=1e-2, anneal=True, scheduler_tol=0)),    # weights change every iteration
+    # (the switch at iteration 31 raises the loss of that epoch: with patience 0 the rate drops there)
+    ("ivae_generic", "IVAE", dict(n_per_seg=30, n_seg=12, d_sources=4, n_layers=2, seed=4, activation="xtanh"),
+     dict(batch_size=100, max_iter=27, seed=7, hidden_dim=30, n_layers=2, lr=1e-2, activation="xtanh", scheduler_tol=0)),
+    ("vae_fused", "VAE", dict(n_per_seg=25, n_seg=20, d_sources=10, n_layers=3, seed=3, activation="lrelu"),
+     dict(batch_size=64, max_iter=45, seed=8, hidden_dim=50, lr=1e-2)),
+]
+
+
+def wrapper_noise_seed(seed, it):
+    return 2_000_000 * (seed + 1) + it
+
+
+def make_wrapper_traces():
+    """Run the reference's `IVAE_wrapper` / `VAE_wrapper` (models/wrappers.py:14-176, cuda=False) with recording shims only:
+    the dataset logs the row order its DataLoader(shuffle=True) asks for (no drop_last: the last batch is ragged), `elbo`
+    seeds the global generator per iteration so that its randn draw can be replayed and logs the loss, the full-data
+    forward at the end is seeded, ReduceLROnPlateau drops `verbose` and logs the rate after every step().  Logger and
+    checkpoints go to a scratch folder; the iterations that got a checkpoint and the Logger's per-epoch means are recorded.
+    -> tests/golden/trace_wrapper.npz, replayed through ivae_amd.runners by tests/test_gpu_wrapper_trace.py."""
+    import argparse
+    import glob
+    import tempfile
+    if not hasattr(np, "int"):
+        np.int = int
+    import models.wrappers as W
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from ivae_amd.data import generate_data
+
+    rec = argparse.Namespace()
+
+    class RecDataset(W.CustomSyntheticDataset):
+        def __getitem__(self, index):
+            rec.order.append(int(index))
+            return super().__getitem__(index)
+
+    def recording(base):
+        class Rec(base):
+            def elbo(self, *a):
+                rec.it += 1
+                if rec.it == 1:
+                    rec.init = {k: v.detach().clone().numpy() for k, v in self.state_dict().items()}
+                torch.manual_seed(wrapper_noise_seed(rec.seed, rec.it))
+                if getattr(self, "anneal_params", False):
+                    rec.coefs.append(tuple(float(t) for t in self._training_hyperparams) + (1.,))
+                else:
+                    rec.coefs.append((1., 1., 1., 1., 1., 0.))
+                e, z = super().elbo(*a)
+                rec.losses.append(-float(e.item()))
+                return e, z
+
+            def forward(self, x, *rest):
+                if x.shape[0] == rec.N:
+                    torch.manual_seed(eval_seed(rec.seed))
+                return super().forward(x, *rest)
+        return Rec
+
+    class RecPlateau(torch.optim.lr_scheduler.ReduceLROnPlateau):
+        def __init__(self, optimizer, *a, verbose=None, **kw):
+            super().__init__(optimizer, *a, **kw)
+
+        def step(self, metrics, *a, **kw):
+            super().step(metrics, *a, **kw)
+            rec.lrs.append(self.optimizer.param_groups[0]["lr"])
+
+    saved = (W.CustomSyntheticDataset, W.iVAE, W.VAE, W.optim.lr_scheduler.ReduceLROnPlateau)
+    W.CustomSyntheticDataset, W.iVAE, W.VAE = RecDataset, recording(W.iVAE), recording(W.VAE)
+    W.optim.lr_scheduler.ReduceLROnPlateau = RecPlateau
+    out, index = {}, []
+    try:
+        for key, which, dkw, wkw in WRAPPER_CASES:
+            S, X, U, _, _ = generate_data(batch_size=0, repeat_linearity=True, **dkw)
+            with tempfile.TemporaryDirectory() as tmp:
+                rec.seed, rec.it, rec.N = wkw["seed"], 0, X.shape[0]
+                rec.order, rec.losses, rec.coefs, rec.lrs = [], [], [], []
+                kw = dict(wkw, cuda=False, log_folder=tmp + "/log/", ckpt_folder=tmp + "/ckpt/")
+                os.makedirs(kw["log_folder"]); os.makedirs(kw["ckpt_folder"])
+                if which == "IVAE":
+                    z, model, params, logger = W.IVAE_wrapper(X, U, S, **kw)
+                else:
+                    z, model, params, logger = W.VAE_wrapper(X, S, **kw)
+                ck = sorted(int(os.path.basename(f).split("_ckpt_")[1].split(".")[0]) for f in glob.glob(tmp + "/**/*_ckpt_*.pth", recursive=True))
+                out[key + ".order"] = np.array(rec.order, np.int32)
+                out[key + ".step_loss"] = np.array(rec.losses, np.float32)
+                out[key + ".step_coef"] = np.array(rec.coefs, np.float64)
+                out[key + ".lr"] = np.array(rec.lrs, np.float64)
+                out[key + ".ckpt_its"] = np.array(ck, np.int64)
+                out[key + ".log_elbo"] = np.array(logger.log_dict["elbo"], np.float64)
+                out[key + ".log_perf"] = np.array(logger.log_dict["perf"], np.float64)
+                out[key + ".z"] = z.detach().numpy()
+                for k, v in rec.init.items():
+                    out[key + ".init." + k] = v
+                index.append(dict(key=key, wrapper=which, data=dkw, kwargs=wkw, n_iter=rec.it, N=int(X.shape[0])))
+                print(f"wrapper trace {key}: {rec.it} iterations, loss {logger.log_dict['elbo']} perf {logger.log_dict['perf']} "
+                      f"lr {rec.lrs} checkpoints at {ck}")
+    finally:
+        W.CustomSyntheticDataset, W.iVAE, W.VAE, W.optim.lr_scheduler.ReduceLROnPlateau = saved
+    out["index"] = np.array(json.dumps(index))
+    np.savez_compressed(os.path.join(OUT, "trace_wrapper.npz"), **out)
+
+
 def make_random_cases(n=24):
     """More reference-made fixtures at random small shapes (round 3): every model class, 1-4 layers, every activation,
     one-hot and dense u, ragged batches, random loss weights for the decomposed ELBO, annealed iVAE at random iterations
@@ -668,6 +777,8 @@ def make_random_cases(n=24):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "wrapper_traces":
+        return make_wrapper_traces()
     if len(sys.argv) > 1 and sys.argv[1] == "random_cases":
         return make_random_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "runner_traces":          # runner_traces [case names to (re)make and merge]
