@@ -71,6 +71,8 @@ def _worker(rank, world, port, B, steps, coef, out):
     (4, 12, dict(a=1000., b=1., c=15., d=1., N=4000., pairwise=True)),       # four ranks, equal shards: the ranks' row blocks must land in rank order
     (3, 13, dict(a=100., b=1., c=.5, d=10., N=4000., pairwise=True)),        # three ranks, shards of 5 / 4 / 4 rows (padded path)
     (4, 14, dict(pairwise=False)),                                           # four ranks, plain ELBO, shards of 4 / 4 / 3 / 3 rows
+    (8, 16, dict(a=100., b=1., c=0., d=10., N=4000., pairwise=True)),        # a whole node's eight ranks, two rows each
+    (8, 19, dict(pairwise=False)),                                           # eight ranks, shards of 3 / 3 / 3 / 2 ... rows
 ])
 def test_ranks_reproduce_single_rank(world, B, coef):
     steps = 3
