@@ -1,13 +1,22 @@
 // Pearson cross-correlation block for the MCC metric, float64 arithmetic on fp32 inputs.
 //
 // Replaces np.corrcoef(x, y, rowvar=False)[:d, d:] (metrics/mcc.py:328; torch spec at
-// mcc.py:174-253): two-pass centred moments.  Pass 1: column sums -> means.  Pass 2: the centred
-// cross moments are the contraction Xc^T Yc over the rows: v_mfma_f64_16x16x4_f64, operands
-// loaded from HBM straight into fragment layout (lane (c, q): row r0 + q, column 16 t + c),
-// converted and centred in registers; the auto moments ride along on the vector unit.  Waves
-// walk 4-row groups grid-strided, per-wave partials meet in LDS and per-block partials in the
-// workspace, both summed in a fixed order (bitwise reproducible for a given n, d).  The
-// Hungarian step (mcc.py:334) stays on the host.
+// mcc.py:174-253).  ONE pass over the rows: moments of the SHIFTED data a = x - kx, b = y - ky
+// (sums, squares, cross products, all float64), where the shift k is the mean of a fixed sample of
+// up to 256 rows spread over the array -- every workgroup forms the same k from the same rows in the
+// same order -- and the centred moments follow as S_ab - S_a S_b / n.  The shift only has to be
+// NEAR the mean: with k the mean of a sample S of the data, n (k - mean)^2 <= (n / |S|) * M2, so
+// the correction term never exceeds n / |S| times the quantity it corrects and float64 keeps
+// >= 12 digits at n = 10^6 whatever the data (offsets, trends, outliers; measured: tools/fuzz_corr.py);
+// a constant column is shifted to exact zeros (the sample sum of equal fp32 values is exact), so its
+// variance is exactly 0 and the correlation nan as in numpy.  The cross moments are the contraction
+// A^T B over the rows: v_mfma_f64_16x16x4_f64, operands loaded from HBM straight into fragment
+// layout (lane (c, q): row r0 + q, column 16 t + c), converted and shifted in registers; sums and
+// squares ride along on the vector unit.  Waves walk 4-row groups grid-strided, per-wave partials
+// meet in LDS and per-block partials in the workspace, both summed in a fixed order (bitwise
+// reproducible for a given n, d).  The Hungarian step (mcc.py:334) stays on the host.
+// (Until round 3 this was two passes -- column means, then centred moments: 130 us at n = 10^6,
+// d = 20, each pass at 2.4 TB/s; the data are now read once.)
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 
@@ -23,41 +32,6 @@ size_t corr_ws_bytes(int64_t n, int d) {
 // block is not finite -- the reference's Hungarian step then raises and the runner scores the batch 0
 // (runners/ivae.py:85-88).  fmin / fmax would turn that nan into -1, i.e. into a perfect |correlation|.
 __device__ __forceinline__ double clip_unit(double c) { return c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c); }
-
-#define CORR_SUM_THREADS 1024
-__global__ __launch_bounds__(CORR_SUM_THREADS) void k_corr_sums(const float* __restrict__ x, const float* __restrict__ y,
-                                                                int64_t n, int d, double* __restrict__ psum) {
-    // thread c < 2d owns a column; rows strided over blocks.  (d is small: <= 64.)  16 waves per CU: the walk is bound by
-    // the bytes in flight
-    __shared__ double red[CORR_SUM_THREADS];
-    const int c = threadIdx.x % (2 * d);
-    const int sub = threadIdx.x / (2 * d);
-    const int nsub = CORR_SUM_THREADS / (2 * d);
-    double acc = 0.0;
-    if (sub < nsub) {
-        const float* src = c < d ? x + c : y + (c - d);
-        // eight rows' loads in flight per thread (a dependent one-load-per-iteration walk is bound by memory latency:
-        // 0.97 ms at n = 10^6, d = 20); the sum keeps its row order
-        const int64_t stride = (int64_t)gridDim.x * nsub;
-        for (int64_t r = (int64_t)blockIdx.x * nsub + sub; r < n; r += 8 * stride) {
-            float vals[8];
-#pragma unroll
-            for (int u_ = 0; u_ < 8; ++u_) {
-                const int64_t rr = r + u_ * stride;
-                vals[u_] = rr < n ? src[rr * d] : 0.f;
-            }
-#pragma unroll
-            for (int u_ = 0; u_ < 8; ++u_) acc += (double)vals[u_];
-        }
-    }
-    red[threadIdx.x] = sub < nsub ? acc : 0.0;
-    __syncthreads();
-    if (threadIdx.x < 2 * d) {
-        double t = 0.0;
-        for (int s = 0; s < nsub; ++s) t += red[s * 2 * d + threadIdx.x];
-        psum[(size_t)blockIdx.x * 2 * d + threadIdx.x] = t;
-    }
-}
 
 // Sums of the nblk <= CORR_BLOCKS per-block partials of up to 64 consecutive quantities [q0, q0 + cnt) by a 1024-thread
 // workgroup: wave w takes blocks 16 w .. 16 w + 15 (16 loads in flight, 512 contiguous bytes each, summed in block order),
@@ -90,47 +64,73 @@ __device__ __forceinline__ void reduce_partials64(const double* __restrict__ p, 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void k_corr_mean(const double* __restrict__ psum, int64_t n, int d, int nblk, double* __restrict__ mean) {
-    __shared__ double red[16 * 64];
-    const int q0 = blockIdx.x * 64;
-    reduce_partials64(psum, 2 * d, nblk, q0, min(64, 2 * d - q0), 1.0 / (double)n, red, mean + q0);
-}
-
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // NT = ceil(d / 16) column tiles of x and of y; WAVES per workgroup (NT <= 2: 16, four per SIMD; else 8: the NT*NT
-// accumulator tiles take 8 registers each).  MFMA slots: A[i = c][k = q] = xc[row q][column 16 ta + c],
-// B[k = q][j = c] = yc[row q][column 16 tb + c]; D[i = 4 r + q][j = c] in register pair r (probed on gfx950: the fp64
+// accumulator tiles take 8 registers each).  MFMA slots: A[i = c][k = q] = a[row q][column 16 ta + c],
+// B[k = q][j = c] = b[row q][column 16 tb + c]; D[i = 4 r + q][j = c] in register pair r (probed on gfx950: the fp64
 // shape interleaves rows where the fp32 16x16x4 shape blocks them).
-template <int NT, int WAVES>
+// Per-block output (nout = d*d + 4d doubles): S_ab (d*d) | S_aa (d) | S_bb (d) | S_a (d) | S_b (d).
+#define CORR_SAMPLE 256
+template <int NT, int WAVES, int U>
 __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __restrict__ x, const float* __restrict__ y,
-                                                            int64_t n, int d, const double* __restrict__ mean,
-                                                            double* __restrict__ pmom) {
+                                                            int64_t n, int d, double* __restrict__ pmom) {
     extern __shared__ __attribute__((aligned(16))) double part[];    // (nout) the block's partial moments
+    __shared__ double red[64 * WAVES];
+    __shared__ double shift[128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
-    const int nout = d * d + 2 * d;
+    const int nout = d * d + 4 * d;
+    {   // the shift: mean of S sample rows r_s = s * (n / S), S a power of two (dividing by it is exact) <= n, <= 256, and
+        // at most 16 rows per thread (all loads in flight at once).  Thread (column c2, sub) sums rows sub, sub + nsub, ...
+        const int c2 = threadIdx.x % (2 * d), sub = threadIdx.x / (2 * d), nsub = 64 * WAVES / (2 * d);
+        int S = 1;
+        while (2 * S <= CORR_SAMPLE && 2 * S <= n && 2 * S <= 16 * nsub) S *= 2;
+        const int64_t rstride = n / S;
+        const float* src = c2 < d ? x + c2 : y + (c2 - d);
+        float vals[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int sidx = sub + e * nsub;
+            vals[e] = sub < nsub && sidx < S ? src[(int64_t)sidx * rstride * d] : 0.f;
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += (double)vals[e];
+        red[threadIdx.x] = sub < nsub ? t : 0.0;
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * d) {
+            double tot = 0.0;
+            for (int k = 0; k < nsub; ++k) tot += red[k * 2 * d + threadIdx.x];
+            shift[threadIdx.x] = tot / (double)S;
+        }
+        __syncthreads();
+    }
     f64x4 acc[NT][NT];
-    double mx[NT], my[NT], sxx[NT], syy[NT];
+    double kx[NT], ky[NT], sxx[NT], syy[NT], sx[NT], sy[NT];
     int col[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         col[t] = min(16 * t + c, d - 1);                     // (a clamped column is loaded and zeroed below)
-        mx[t] = mean[col[t]]; my[t] = mean[d + col[t]];
-        sxx[t] = 0.0; syy[t] = 0.0;
+        kx[t] = shift[col[t]]; ky[t] = shift[d + col[t]];
+        sxx[t] = 0.0; syy[t] = 0.0; sx[t] = 0.0; sy[t] = 0.0;
 #pragma unroll
         for (int u = 0; u < NT; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
     }
-    constexpr int U = 4;                                      // 4-row groups in flight per wave: 2 NT U loads
+    // U 4-row groups per batch of loads, two batches in flight per wave (the next batch is requested before the current one
+    // is consumed: a wave that waits for its loads, then computes, then asks again leaves the memory idle while it computes
+    // and the matrix pipe idle while it waits -- 4 waves per SIMD do not cover that)
+    // (U = 2 where 4 would spill: the NT * NT accumulator tiles take 8 registers each)
     const int64_t ngroups = (n + 3) / 4;
     const int64_t stride = (int64_t)gridDim.x * WAVES;
-    for (int64_t g0 = (int64_t)blockIdx.x * WAVES + w; g0 < ngroups; g0 += U * stride) {
-        float xv[U][NT], yv[U][NT];
+    auto fetch = [&](int64_t g0, float (&xv)[U][NT], float (&yv)[U][NT]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t row = min((g0 + u * stride) * 4 + q, n - 1);     // (clamped: zeroed below)
+            const int64_t row = min((g0 + u * stride) * 4 + q, n - 1);     // (clamped: zeroed in consume)
 #pragma unroll
             for (int t = 0; t < NT; ++t) { xv[u][t] = x[row * d + col[t]]; yv[u][t] = y[row * d + col[t]]; }
         }
+    };
+    auto consume = [&](int64_t g0, const float (&xv)[U][NT], const float (&yv)[U][NT]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t row = (g0 + u * stride) * 4 + q;
@@ -139,8 +139,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __rest
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const bool ok = rok && 16 * t + c < d;
-                a[t] = ok ? (double)xv[u][t] - mx[t] : 0.0;
-                b[t] = ok ? (double)yv[u][t] - my[t] : 0.0;
+                a[t] = ok ? (double)xv[u][t] - kx[t] : 0.0;
+                b[t] = ok ? (double)yv[u][t] - ky[t] : 0.0;
+                sx[t] += a[t];
+                sy[t] += b[t];
                 sxx[t] += a[t] * a[t];
                 syy[t] += b[t] * b[t];
             }
@@ -150,17 +152,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __rest
                 for (int tb = 0; tb < NT; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
         }
+    };
+    {
+        float xa[U][NT], ya[U][NT], xb[U][NT], yb[U][NT];
+        int64_t g0 = (int64_t)blockIdx.x * WAVES + w;
+        fetch(g0, xa, ya);
+        for (; g0 < ngroups; g0 += 2 * U * stride) {
+            fetch(g0 + U * stride, xb, yb);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(g0, xa, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(g0 + 2 * U * stride, xa, ya);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g0 + U * stride < ngroups) consume(g0 + U * stride, xb, yb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // wave partials -> one LDS block, wave after wave (a fixed order: deterministic).  Cross moments from the accumulators;
-    // auto moments: the four q lanes of a column summed in q order first
+    // sums and squares: the four q lanes of a column summed in q order first
+    auto over_q = [&](double v) {
+        const double v1 = __shfl(v, c + 16), v2 = __shfl(v, c + 32), v3 = __shfl(v, c + 48);
+        return ((v + v1) + v2) + v3;
+    };
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const double vx = sxx[t], vy = syy[t];
-        const double x1 = __shfl(vx, c + 16), x2 = __shfl(vx, c + 32), x3 = __shfl(vx, c + 48);
-        const double y1 = __shfl(vy, c + 16), y2 = __shfl(vy, c + 32), y3 = __shfl(vy, c + 48);
-        sxx[t] = ((vx + x1) + x2) + x3;
-        syy[t] = ((vy + y1) + y2) + y3;
-    }
+    for (int t = 0; t < NT; ++t) { sxx[t] = over_q(sxx[t]); syy[t] = over_q(syy[t]); sx[t] = over_q(sx[t]); sy[t] = over_q(sy[t]); }
     for (int ww = 0; ww < WAVES; ++ww) {
         if (w == ww) {
 #pragma unroll
@@ -175,9 +190,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __rest
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (q == 0 && 16 * t + c < d) {
-                    const int ox = d * d + 16 * t + c, oy = ox + d;
-                    part[ox] = (ww ? part[ox] : 0.0) + sxx[t];
-                    part[oy] = (ww ? part[oy] : 0.0) + syy[t];
+                    const int o = d * d + 16 * t + c;
+                    part[o] = (ww ? part[o] : 0.0) + sxx[t];
+                    part[o + d] = (ww ? part[o + d] : 0.0) + syy[t];
+                    part[o + 2 * d] = (ww ? part[o + 2 * d] : 0.0) + sx[t];
+                    part[o + 3 * d] = (ww ? part[o + 3 * d] : 0.0) + sy[t];
                 }
         }
         __syncthreads();
@@ -186,20 +203,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __rest
 }
 
 // Workgroup b: correlations of the cross moments o in [64 b, 64 b + 64); it reduces those and (again in every workgroup:
-// 2d more quantities) the auto moments it divides by.
+// 4d more quantities) the squares and sums that centre and normalise them.
 __global__ __launch_bounds__(1024) void k_corr_final(const double* __restrict__ pmom, int64_t n, int d, int nblk,
                                                      double* __restrict__ cc) {
     __shared__ double red[16 * 64];
     __shared__ double cross[64];
-    __shared__ double autos[128];
-    const int nout = d * d + 2 * d, o0 = blockIdx.x * 64, cnt = min(64, d * d - o0);
-    const double scale = 1.0 / (double)(n - 1);            // np.cov normalisation (cancels in the ratio)
-    reduce_partials64(pmom, nout, nblk, o0, cnt, scale, red, cross);
-    for (int a0 = 0; a0 < 2 * d; a0 += 64) reduce_partials64(pmom, nout, nblk, d * d + a0, min(64, 2 * d - a0), scale, red, autos + a0);
+    __shared__ double lin[256];               // S_aa (d) | S_bb (d) | S_a (d) | S_b (d)
+    const int nout = d * d + 4 * d, o0 = blockIdx.x * 64, cnt = min(64, d * d - o0);
+    reduce_partials64(pmom, nout, nblk, o0, cnt, 1.0, red, cross);
+    for (int a0 = 0; a0 < 4 * d; a0 += 64) reduce_partials64(pmom, nout, nblk, d * d + a0, min(64, 4 * d - a0), 1.0, red, lin + a0);
     if ((int)threadIdx.x < cnt) {
         const int o = o0 + threadIdx.x, a = o / d, b = o - a * d;
-        double c = cross[threadIdx.x] / sqrt(autos[a]);
-        c = c / sqrt(autos[d + b]);
+        const double inv_n = 1.0 / (double)n, scale = 1.0 / (double)(n - 1);     // np.cov normalisation (cancels in the ratio)
+        const double sa = lin[2 * d + a], sb = lin[3 * d + b];
+        const double cov = (cross[threadIdx.x] - sa * sb * inv_n) * scale;
+        const double va = (lin[a] - sa * sa * inv_n) * scale, vb = (lin[d + b] - sb * sb * inv_n) * scale;
+        double c = cov / sqrt(va);
+        c = c / sqrt(vb);
         cc[o] = clip_unit(c);
     }
 }
@@ -283,19 +303,15 @@ hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks,
 }
 
 hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double* cc, double* ws, hipStream_t st) {
-    double* mean = ws;
-    double* psum = mean + 2 * d;
-    double* pmom = psum + (size_t)CORR_BLOCKS * 2 * d;
+    double* pmom = ws;                      // (nblk, d*d + 4d): inside what corr_ws_bytes has always asked for
     int nblk = (int)((n + CORR_ROWS - 1) / CORR_ROWS);
     if (nblk > CORR_BLOCKS) nblk = CORR_BLOCKS;
-    const size_t smem = (size_t)(d * d + 2 * d) * sizeof(double);          // d = 64: 33 792 B
-    hipLaunchKernelGGL(k_corr_sums, dim3(nblk), dim3(CORR_SUM_THREADS), 0, st, x, y, n, d, psum);
-    hipLaunchKernelGGL(k_corr_mean, dim3((2 * d + 63) / 64), dim3(1024), 0, st, psum, n, d, nblk, mean);
+    const size_t smem = (size_t)(d * d + 4 * d) * sizeof(double);          // d = 64: 34 816 B
     switch ((d + 15) / 16) {
-        case 1: hipLaunchKernelGGL((k_corr_moments<1, 16>), dim3(nblk), dim3(1024), smem, st, x, y, n, d, mean, pmom); break;
-        case 2: hipLaunchKernelGGL((k_corr_moments<2, 16>), dim3(nblk), dim3(1024), smem, st, x, y, n, d, mean, pmom); break;
-        case 3: hipLaunchKernelGGL((k_corr_moments<3, 8>), dim3(nblk), dim3(512), smem, st, x, y, n, d, mean, pmom); break;
-        case 4: hipLaunchKernelGGL((k_corr_moments<4, 8>), dim3(nblk), dim3(512), smem, st, x, y, n, d, mean, pmom); break;
+        case 1: hipLaunchKernelGGL((k_corr_moments<1, 16, 4>), dim3(nblk), dim3(1024), smem, st, x, y, n, d, pmom); break;
+        case 2: hipLaunchKernelGGL((k_corr_moments<2, 16, 2>), dim3(nblk), dim3(1024), smem, st, x, y, n, d, pmom); break;
+        case 3: hipLaunchKernelGGL((k_corr_moments<3, 8, 4>), dim3(nblk), dim3(512), smem, st, x, y, n, d, pmom); break;
+        case 4: hipLaunchKernelGGL((k_corr_moments<4, 8, 2>), dim3(nblk), dim3(512), smem, st, x, y, n, d, pmom); break;
         default: return hipErrorInvalidValue;
     }
     hipLaunchKernelGGL(k_corr_final, dim3((d * d + 63) / 64), dim3(1024), 0, st, pmom, n, d, nblk, cc);
@@ -303,8 +319,8 @@ hipError_t launch_corr(const float* x, const float* y, int64_t n, int d, double*
 }
 
 // ---- the same computation with the scratch inside the library: ivae_corr_static (callers that cannot allocate) ----
-// `scratch` holds what ivae_corr's workspace argument holds (column means, per-block column sums, per-block centred
-// moments) for d <= CORR_STATIC_MAX_D.  In host code the array's NAME is only a stand-in: the address the kernels get is
+// `scratch` holds what ivae_corr's workspace argument holds (the per-block moments; sized as corr_ws_bytes asks)
+// for d <= CORR_STATIC_MAX_D.  In host code the array's NAME is only a stand-in: the address the kernels get is
 // the one hipGetSymbolAddress returns for the CURRENT device (every GPU holds its own copy), looked up once per device
 // and kept in scratch_ptr[].  Nothing here must start at zero: every word a kernel reads was written by the kernel
 // before it in the same call (blocks 0..nblk-1 only), so a call does not depend on what the last one left.

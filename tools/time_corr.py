@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time ivae_corr (the MCC correlation block of a full-data evaluation) at N = 10^6, d = 20 (BASELINE configs[3]'s eval)
-and at N = 40000, d = 10; prints microseconds per call and the HBM rate the two passes over x, y amount to."""
+and at N = 40000, d = 10; prints microseconds per call and the HBM rate that reading x and y once amounts to."""
 import os
 import sys
 
@@ -22,4 +22,4 @@ for n, d in ((1_000_000, 20), (40_000, 10), (1_000_000, 40)):
     e1.record()
     torch.cuda.synchronize()
     us = 1e3 * e0.elapsed_time(e1) / 20
-    print(f"ivae_corr n={n} d={d}: {us:.1f} us per call, {2 * 2 * n * d * 4 / us / 1e6:.2f} TB/s over two passes of x and y")
+    print(f"ivae_corr n={n} d={d}: {us:.1f} us per call, {2 * n * d * 4 / us / 1e6:.2f} TB/s (x and y are read once)")
