@@ -249,9 +249,10 @@ def run_dp(args, rank, world, dev):
            "config": {"workload": "BASELINE configs[3]: iVAE d=20, 200 segments, 3-layer lrelu MLPs hidden 50, global batch "
                                   "4096, plain ELBO + Adam", "global_batch": B, "rows_per_rank": hi - lo,
                       "collective": ("none (one rank)" if world == 1 else
-                                     "RCCL all-reduce(sum) of [gradient | loss] (%d floats) per step, world size %d" % (
+                                     "%s all-reduce(sum) of [gradient | loss] (%d floats) per step, world size %d" % (
+                                         "RCCL" if BACKEND == "nccl" else BACKEND + " [REHEARSAL: ranks share GPUs, not a measurement]",
                                          params.numel() + 1, world)),
-                      "backend": "nccl" if world > 1 else None, "impl": "shape-generic kernels (k_chain, k_wgrad, k_reduce+Adam)",
+                      "backend": BACKEND if world > 1 else None, "impl": "shape-generic kernels (k_chain, k_wgrad, k_reduce+Adam)",
                       "parallelism": "dp%d" % world},
            "final_loss": round(float(loss[0]), 3),
            "roofline": {"bound": "mfma", "kernel": "one step's launches on rank 0 (HIP events around the K steps, collective included)",
@@ -267,13 +268,19 @@ def run_dp(args, rank, world, dev):
     print(json.dumps(out))
 
 
+# "nccl" (= RCCL) always, except when tests rehearse the N > 1 path of this file on a one-GPU box: IVAE_BENCH_BACKEND=gloo
+# lets the ranks share a GPU (RCCL refuses two ranks on one device); such a line says so in config.parallelism and is not a
+# measurement of anything.
+BACKEND = os.environ.get("IVAE_BENCH_BACKEND", "nccl")
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run as a CHILD
     process, before this process touches the GPU) and leave with its exit code."""
     import socket
     import subprocess
     have = torch.cuda.device_count()          # counts devices without initialising the GPU runtime
-    if n > have:
+    if n > have and BACKEND == "nccl":
         sys.exit("bench.py: --gpus %d asked for, %d GPU(s) visible; refusing to report a smaller run as N=%d" % (n, have, n))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -312,9 +319,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if BACKEND != "nccl":                     # rehearsal on a box with fewer GPUs than ranks: the ranks share the GPUs there are
+        local_rank %= torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if BACKEND == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(BACKEND)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -398,7 +410,8 @@ def main():
                                    "hidden 50, batch 64, plain ELBO + Adam lr 1e-2",
                        "models_per_gpu": M, "batch": B, "impl": tr.impl, "rng": tr.rng,
                        "device_warmup_ms": args.spinup_ms,
-                       "parallelism": "independent model sets per GPU, no collective"},
+                       "parallelism": "independent model sets per GPU, no collective" + (
+                           "" if BACKEND == "nccl" else " [REHEARSAL over %s: ranks share GPUs, not a measurement]" % BACKEND)},
             "per_model": {"steps_per_s": round(args.steps / dt, 1), "samples_per_s": round(args.steps * B / dt, 1)},
             "final_mean_loss": round(loss, 3),
             "roofline": {"bound": "mfma", "kernel": tr.dominant_kernel, "achieved": round(achieved, 4),
