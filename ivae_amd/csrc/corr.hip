@@ -153,19 +153,81 @@ __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __rest
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
         }
     };
+    // The walk is bound by vector-instruction issue, not by memory (timing-only ablations: every vector instruction taken
+    // out of the loop shortens it by its issue time, fp64 ones by 8 cycles each), so the steady state spends none on
+    // addresses or masks: batches whose rows all exist are loaded through a buffer descriptor -- per-lane byte offsets
+    // fixed for the whole walk, the batch position in the scalar offset -- and consumed unmasked (a lane whose column is
+    // clamped computes on a duplicate column; nothing it produces is written).  Two batches per trip, the next one
+    // requested before the current one is consumed.  Arrays of 4 GB and more, and the last (partial) batches, take the
+    // masked 64-bit path below.
+    int64_t g0 = (int64_t)blockIdx.x * WAVES + w;
+    const int64_t step = U * stride;
+    if ((uint64_t)n * (uint64_t)d * 4u < (1ull << 32)) {
+        const int64_t nfull = n / 4;                         // groups whose four rows all exist
+        // batches of this wave that are complete: the last group of batch b is g0 + (b U + U - 1) stride
+        const int64_t last0 = g0 + (int64_t)(U - 1) * stride;
+        const int full = last0 < nfull ? (int)((nfull - 1 - last0) / step) + 1 : 0;
+        const int trips = __builtin_amdgcn_readfirstlane(full / 2);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((uint64_t)n * d * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, (int)((uint64_t)n * d * 4u), 0x00020000);
+        int vo[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) vo[t] = (int)(((g0 * 4 + q) * d + col[t]) * 4);
+        const int ustep = __builtin_amdgcn_readfirstlane((int)(stride * 16 * d));      // bytes from a group to the wave's next
+        auto bfetch = [&](int so, float (&xv)[U][NT], float (&yv)[U][NT]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    xv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo[t], so + u * ustep, 0));
+                    yv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo[t], so + u * ustep, 0));
+                }
+        };
+        auto bconsume = [&](const float (&xv)[U][NT], const float (&yv)[U][NT]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double a[NT], b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    a[t] = (double)xv[u][t] - kx[t];
+                    b[t] = (double)yv[u][t] - ky[t];
+                    sx[t] += a[t];
+                    sy[t] += b[t];
+                    sxx[t] += a[t] * a[t];
+                    syy[t] += b[t] * b[t];
+                }
+#pragma unroll
+                for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NT; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            }
+        };
+        if (trips > 0) {
+            float xa[U][NT], ya[U][NT], xb[U][NT], yb[U][NT];
+            const int bstep = U * ustep;
+            int so = 0;
+            bfetch(so, xa, ya);
+            for (int it = 0; it < trips; ++it) {
+                bfetch(so + bstep, xb, yb);
+                __builtin_amdgcn_sched_barrier(0);
+                bconsume(xa, ya);
+                __builtin_amdgcn_sched_barrier(0);
+                // (the request past the last trip reads rows that exist or, past the end of the array, zeros: never used)
+                bfetch(so + 2 * bstep, xa, ya);
+                __builtin_amdgcn_sched_barrier(0);
+                bconsume(xb, yb);
+                __builtin_amdgcn_sched_barrier(0);
+                so += 2 * bstep;
+            }
+            g0 += (int64_t)trips * 2 * step;
+        }
+    }
     {
-        float xa[U][NT], ya[U][NT], xb[U][NT], yb[U][NT];
-        int64_t g0 = (int64_t)blockIdx.x * WAVES + w;
-        fetch(g0, xa, ya);
-        for (; g0 < ngroups; g0 += 2 * U * stride) {
-            fetch(g0 + U * stride, xb, yb);
-            __builtin_amdgcn_sched_barrier(0);
+        float xa[U][NT], ya[U][NT];
+        for (; g0 < ngroups; g0 += step) {
+            fetch(g0, xa, ya);
             consume(g0, xa, ya);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(g0 + 2 * U * stride, xa, ya);
-            __builtin_amdgcn_sched_barrier(0);
-            if (g0 + U * stride < ngroups) consume(g0 + U * stride, xb, yb);
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // wave partials -> one LDS block, wave after wave (a fixed order: deterministic).  Cross moments from the accumulators;
