@@ -15,6 +15,7 @@ Shuffling and noise come from torch's device generators, so trajectories match t
 (same distribution of permutations and of eps), not draw for draw; tests/test_gpu_e2e.py replays recorded
 reference permutations and eps through the same kernels for the draw-for-draw check.
 """
+import itertools
 import time
 
 import numpy as np
@@ -48,13 +49,34 @@ def _epoch_batches(n, batch_size, drop_last, device, generator):
     return [perm[i:i + batch_size] for i in range(0, stop, batch_size)]
 
 
+_PERMS = {}
+
+
 def _assignment_scores(cc_abs):
     """Mean matched |correlation| per block (metrics/mcc.py:333-335); 0 where the block is not finite, like the
-    bare `except: perf = 0` of runners/ivae.py:85-88."""
-    out = []
-    for cc in cc_abs:
-        out.append(float(cc[linear_sum_assignment(-1 * cc)].mean()) if np.isfinite(cc).all() else 0.)
-    return out
+    bare `except: perf = 0` of runners/ivae.py:85-88.
+
+    The reference solves one assignment problem per training step on the host (scipy); an epoch of K packed seeds is
+    625 K of them, which at K = 64 cost more host time than the epoch's kernels cost GPU time.  Up to d = 6 the d!
+    assignments are therefore scored for all blocks at once in numpy (the optimum is the optimum however it is found; the
+    score is formed from the matched entries exactly as the reference forms it); wider blocks go through scipy one by one."""
+    cc_abs = np.asarray(cc_abs)
+    n = cc_abs.shape[0]
+    d = cc_abs.shape[-1] if cc_abs.ndim == 3 else 0
+    if n == 0 or d == 0 or d > 6 or cc_abs.shape[1] != d:
+        return [float(cc[linear_sum_assignment(-1 * cc)].mean()) if np.isfinite(cc).all() else 0. for cc in cc_abs]
+    if d not in _PERMS:
+        perms = np.array(list(itertools.permutations(range(d))), dtype=np.intp)                  # (d!, d)
+        onehot = np.zeros((len(perms), d * d))
+        onehot[np.arange(len(perms))[:, None], np.arange(d)[None, :] * d + perms] = 1.          # assignment -> its d entries
+        _PERMS[d] = perms, np.ascontiguousarray(onehot.T)
+    perms, onehot_t = _PERMS[d]
+    rows = np.arange(d)
+    finite = np.isfinite(cc_abs).all((1, 2))
+    safe = np.where(finite[:, None, None], cc_abs, 0.)
+    best = (safe.reshape(n, d * d) @ onehot_t).argmax(1)                     # totals of all d! assignments: one matrix product
+    matched = safe[np.arange(n)[:, None], rows[None, :], perms[best]]        # (n, d), row order as scipy returns it
+    return [float(v) for v in np.where(finite, matched.mean(-1), 0.)]
 
 
 # ------------------------------------------------------------------------------------------------ family A
@@ -167,6 +189,14 @@ def runner(args, config, *, replay=None, trace=None, init_seeds=False, init_pert
     loss_hists, perf_hists = [[] for _ in seeds], [[] for _ in seeds]
     tag = (lambda i: '') if K == 1 else (lambda i: '[seed {}] '.format(seeds[i]))
 
+    def finish(epoch, train_loss, cc_host):
+        scores = np.array(_assignment_scores(cc_host), dtype=np.float64).reshape(nb, K).sum(0) / nb
+        for i in range(K):
+            perf_hists[i].append(float(scores[i]))
+            print('{}==> Epoch {}/{}:\ttrain loss: {:.6f}\ttrain perf: {:.6f}'.format(tag(i), epoch, config.epochs,
+                                                                                       train_loss[i], scores[i]))
+
+    pending = None
     for epoch in range(1, config.epochs + 1):
         for model in models:
             model.train()
@@ -189,23 +219,29 @@ def runner(args, config, *, replay=None, trace=None, init_seeds=False, init_pert
         losses, _ = pack.epoch(Xe, Ue, a, b, c, d, N, eps=eps, z_out=Ze)              # (nb, K)
         # the per-step batch scores (runners/ivae.py:86) of all seeds, one launch per epoch
         cc = ops.corr_batched(Se.reshape(nb * K, B, d_latent), Ze.view(nb * K, B, d_latent))
+        # The assignment problems of the PREVIOUS epoch's batch scores are host work (Hungarian step on the host, as in the
+        # reference): they are solved here, while the GPU runs the launches just queued -- those needed the previous epoch's
+        # losses (the schedulers below) but not its scores.  An epoch's line is printed one epoch late, in order.
+        if pending is not None:
+            finish(*pending)
+            pending = None
         # the epoch's one sync; summed as the reference does (`train_loss += loss.item()`, runners/ivae.py:84,112: float64,
         # step by step), which also makes a seed's figure independent of how many seeds are packed beside it -- for
         # packs of fewer than 128 models: from 128 on the in-workgroup pairwise kernel walks with 4 waves per model instead
         # of 16 / 8 and sums its partials in another grouping (last-bit differences, tests/test_gpu_sweep.py)
         train_loss = losses.cpu().numpy().astype(np.float64).sum(0) / nb
-        scores = np.array(_assignment_scores(cc.abs().cpu().numpy()), dtype=np.float64).reshape(nb, K).sum(0) / nb
+        cc_host = cc.abs().cpu().numpy()
         for i in range(K):
             loss_hists[i].append(float(train_loss[i]))
-            perf_hists[i].append(float(scores[i]))
-            print('{}==> Epoch {}/{}:\ttrain loss: {:.6f}\ttrain perf: {:.6f}'.format(tag(i), epoch, config.epochs,
-                                                                                       train_loss[i], scores[i]))
             if not config.no_scheduler:
                 schedulers[i].step(float(train_loss[i]))
         if trace is not None:
             trace.setdefault('step_loss', []).append(losses.cpu())
             trace.setdefault('coef', []).append((a, b, c, d))
             trace.setdefault('lr', []).append([opt.param_groups[0]['lr'] for opt in pack.optimizers])
+        pending = (epoch, train_loss, cc_host)
+    if pending is not None:
+        finish(*pending)
     print('\ntotal runtime: {}'.format(time.time() - st))
 
     # full-dataset score on a SAMPLE of q(z|x,u), as the reference does (runners/ivae.py:118-123)
