@@ -85,9 +85,12 @@ class RunLog:
         """`val` is one observation, or (with weight=k) the SUM of k observations."""
         self._means[key].add(val, weight)
 
-    def log(self):
-        for key, mean in self._means.items():
-            self.log_dict[key].append(mean.value())
+    def log(self, keys=None):
+        """Close the current averaging window (utils/utils.py:150-156).  `keys` (not in the reference): only these keys --
+        the training loops log an epoch's loss when the epoch ends and its batch scores one epoch later, when the host has
+        worked them out under the next epoch's launches."""
+        for key in (self._means if keys is None else keys):
+            self.log_dict[key].append(self._means[key].value())
             self._means[key] = _Mean()
 
     def get_last(self, key):

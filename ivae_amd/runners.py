@@ -355,9 +355,22 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
         vals = logger.log_dict[key]
         return vals[-1] if vals else float('nan')       # (the reference would raise here inside the first epoch)
 
+    pending = []          # [(epoch, mean loss, |correlation| blocks on the host)] of the epoch whose scores are still due
+
+    def finish_scores():
+        """The batch scores (wrappers.py:75) of the epoch before: assignment problems on the host, solved while the GPU runs
+        the launches of the current epoch (which needed that epoch's loss for the scheduler, not its scores)."""
+        while pending:
+            ep, elbo, cc_host = pending.pop(0)
+            for score in _assignment_scores(cc_host):
+                logger.update('perf', score)
+            logger.log(keys=('perf',))
+            print('epoch {}/{} \tloss: {}\tperf: {}'.format(ep, max_epochs, elbo, logger.get_last('perf')))
+
     def maybe_checkpoint(it):
         """wrappers.py:78-80: a checkpoint whenever `it` is a multiple of max_iter / 5, holding the state AT that iteration."""
         if ckpt_folder is not None and ckpt_every > 0 and it % ckpt_every == 0:
+            finish_scores()                   # the checkpoint stores the last logged epoch's loss and score
             opt = drv.as_optimizer() if fused else optimizer
             if trace is not None:
                 trace.setdefault('ckpt_its', []).append(it)
@@ -470,18 +483,18 @@ def _train_family_b(model, dset, S, batch_size, max_iter, lr, device, anneal, lo
                 maybe_checkpoint(it)
             if Ze is not None and n_full:
                 cc[:n_full] = ops.corr_batched(Ze, Z[torch.stack(batches[:n_full]).view(-1)].view(n_full, batch_size, d))
+        finish_scores()                       # the previous epoch's, under this epoch's launches (all queued by now)
         if cc is not None:
-            for score in _assignment_scores(cc.abs().cpu().numpy()):
-                logger.update('perf', score)
-        logger.log()
+            cc_host = cc.abs().cpu().numpy()
+            logger.log(keys=('elbo',))
+            pending.append((epoch, logger.get_last('elbo'), cc_host))
+        else:
+            logger.log()
+            print('epoch {}/{} \tloss: {}'.format(epoch, max_epochs, logger.get_last('elbo')))
         scheduler.step(logger.get_last('elbo'))
         if trace is not None:
             trace.setdefault('lr', []).append(scheduler.optimizer.param_groups[0]['lr'])
-        if S is not None:
-            print('epoch {}/{} \tloss: {}\tperf: {}'.format(epoch, max_epochs, logger.get_last('elbo'),
-                                                            logger.get_last('perf')))
-        else:
-            print('epoch {}/{} \tloss: {}'.format(epoch, max_epochs, logger.get_last('elbo')))
+    finish_scores()
 
     with torch.no_grad():
         ev = None if replay is None else replay.eval_eps().to(device)
