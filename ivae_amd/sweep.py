@@ -23,7 +23,7 @@ import torch.distributed as dist
 from scipy.optimize import linear_sum_assignment
 
 from . import ops
-from .data import generate_data
+from .data import dataset_path, generate_data
 from .dist import gather_model_results, model_range
 from .trainer import FusedPackedTrainer, PackedTrainer, PlateauLR
 
@@ -55,18 +55,31 @@ def device_datasets(n_models, n_seg, n_per_seg, d, seeds, device):
 
 
 def _host_dataset(job):
-    n_seg, n_per_seg, d, sd = job
-    S, X, U, _, _ = generate_data(n_per_seg, n_seg, d, n_layers=3, seed=int(sd), prior='gauss', activation='lrelu',
+    n_seg, n_per_seg, d, sd, cache = job
+    path = None
+    if cache:       # the reference's own cache (data/data.py:357-372: same file name, same keys): either code base reads it
+        path = dataset_path(cache, n_per_seg, n_seg, d, d, 3, int(sd), 'gauss', 'lrelu')
+        if os.path.exists(path):
+            with np.load(path) as z:
+                return tuple(np.ascontiguousarray(z[k], np.float32) for k in ('x', 'u', 's'))
+    S, X, U, M, L = generate_data(n_per_seg, n_seg, d, n_layers=3, seed=int(sd), prior='gauss', activation='lrelu',
                                   repeat_linearity=True)
+    if path is not None:
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        tmp = '{}.{}.tmp.npz'.format(path, os.getpid())
+        np.savez_compressed(tmp, s=S, x=X, u=U, m=M, L=L)
+        os.replace(tmp, path)            # (whole files only: another rank may be looking for the same dataset)
     return tuple(np.ascontiguousarray(a, np.float32) for a in (X, U, S))
 
 
-def host_datasets_numpy(n_seg, n_per_seg, jobs, workers=None):
+def host_datasets_numpy(n_seg, n_per_seg, jobs, workers=None, cache=None):
     """The bit-exact host generator (ivae_amd.data.generate_data == data/data.py:200-304, repeat_linearity=True as
     data.py:369), one dataset per (d, seed) job -> {(d, seed): (X, U, S)}.  The datasets are independent (the generator
     seeds the legacy numpy stream per dataset), so they are made by a pool of forked workers -- only while this process
-    has not initialised the GPU (a fork of a process that holds a HIP context is not safe); afterwards one by one."""
-    args = [(n_seg, n_per_seg, d, sd) for d, sd in jobs]
+    has not initialised the GPU (a fork of a process that holds a HIP context is not safe); afterwards one by one.
+    `cache`: a folder (with trailing separator, as the reference's `data_path`) of `.npz` files in the reference's cache format;
+    datasets found there are loaded instead of generated, the others are generated and left there."""
+    args = [(n_seg, n_per_seg, d, sd, cache) for d, sd in jobs]
     workers = min(workers or 16, len(args), os.cpu_count() or 1)
     if workers > 1 and not torch.cuda.is_initialized():
         import multiprocessing as mp
@@ -201,6 +214,9 @@ def main():
                     help="host (default): the bit-exact numpy generator of data/data.py, as north_star asks (seconds per "
                          "dataset); device: a throughput-only stand-in drawn on the GPU WITHOUT the generator's "
                          "condition-number rejection -- its MCCs are not on reference inputs")
+    ap.add_argument("--data-path", default=None,
+                    help="folder for the host generator's datasets in the reference's cache format (tcl_*.npz, data/data.py:357-372): "
+                         "generated once, loaded afterwards (a full-length sweep spends 7x its training time generating them)")
     ap.add_argument("--no-scheduler", action="store_true", help="constant learning rate (the reference's no_scheduler: True); "
                                                                 "default: every run has its own ReduceLROnPlateau(factor .1, patience 0)")
     ap.add_argument("--serial", action="store_true", help="train one pack (latent dimension) at a time instead of all "
@@ -215,7 +231,8 @@ def main():
     if args.data == "host":      # the host generator's worker pool forks: before this process initialises the GPU
         runs = [(d, s) for d in dims for s in range(args.seeds)]
         lo, hi = model_range(len(runs), rank, world)
-        made = host_datasets_numpy(args.ns, args.nps, runs[lo:hi], workers=max(1, 16 // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+        made = host_datasets_numpy(args.ns, args.nps, runs[lo:hi], workers=max(1, 16 // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))),
+                                   cache=None if args.data_path is None else os.path.join(args.data_path, ""))
     t_data = time.perf_counter() - t0
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -59,3 +59,22 @@ def test_condition_number_trials_are_the_reference_loop_bit_for_bit(ds, dd):
     assert got.dtype == want.dtype and np.array_equal(got, want)
     assert np.random.uniform() == after_loop
     assert np.percentile(list(want), 25) == np.percentile(got, 25)
+
+
+def test_sweep_dataset_cache_round_trip(tmp_path):
+    """`python -m ivae_amd.sweep --data-path DIR`: datasets are left in the reference's cache format (file name and keys of
+    data/data.py:357-372) and loaded on the next run -- the same arrays as a fresh generation, bit for bit."""
+    from ivae_amd.data import dataset_path
+    from ivae_amd.sweep import host_datasets_numpy
+    jobs = [(3, 0), (3, 1), (4, 0)]
+    root = str(tmp_path) + os.sep
+    made = host_datasets_numpy(5, 100, jobs, cache=root)
+    for d, sd in jobs:
+        path = dataset_path(root, 100, 5, d, d, 3, sd, "gauss", "lrelu")
+        with np.load(path) as z:
+            assert sorted(z.files) == ["L", "m", "s", "u", "x"]
+    again = host_datasets_numpy(5, 100, jobs, cache=root)          # loaded
+    fresh = host_datasets_numpy(5, 100, jobs)                       # generated
+    for k in jobs:
+        for a, b, c in zip(made[k], again[k], fresh[k]):
+            assert a.dtype == np.float32 and np.array_equal(a, b) and np.array_equal(a, c)
