@@ -206,6 +206,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __rest
         if (trips > 0) {
             float xa[U][NT], ya[U][NT], xb[U][NT], yb[U][NT];
             const int bstep = U * ustep;
+            const int so_last = (2 * trips - 1) * bstep;      // the last complete batch of this wave
             int so = 0;
             bfetch(so, xa, ya);
             for (int it = 0; it < trips; ++it) {
@@ -213,8 +214,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_corr_moments(const float* __rest
                 __builtin_amdgcn_sched_barrier(0);
                 bconsume(xa, ya);
                 __builtin_amdgcn_sched_barrier(0);
-                // (the request past the last trip reads rows that exist or, past the end of the array, zeros: never used)
-                bfetch(so + 2 * bstep, xa, ya);
+                // (the request of the last trip has no batch to fetch: it reads the last one again, unused; no branch here,
+                //  so that the wait counts stay counted.  A request past the array would be harmless too -- on gfx950 the
+                //  scalar offset is part of a raw buffer load's range check, tools/ubench/soffset_range.hip -- but is not made)
+                bfetch(min(so + 2 * bstep, so_last), xa, ya);
                 __builtin_amdgcn_sched_barrier(0);
                 bconsume(xb, yb);
                 __builtin_amdgcn_sched_barrier(0);
