@@ -289,81 +289,146 @@ __global__ __launch_bounds__(1024) void k_corr_final(const double* __restrict__ 
     }
 }
 
-// Many small problems in ONE launch: block b owns rows [b*n, (b+1)*n) of x and y (the per-step batch scores of a
-// training epoch, runners/ivae.py:86, wrappers.py:75: n = batch size).  Same two-pass centred moments in float64,
-// everything inside the workgroup: column means -> centred 64-row chunks in LDS -> moments -> correlation block.
-__global__ __launch_bounds__(256) void k_corr_batched(const float* __restrict__ x, const float* __restrict__ y, int64_t n,
-                                                      int d, double* __restrict__ cc) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int ld = 2 * d + 1, nout = d * d + 2 * d;
-    double* tile = sm;                          // CORR_ROWS x (2d+1)
-    double* mean = tile + CORR_ROWS * ld;       // 2d
-    double* mom = mean + 2 * d;                 // d*d + 2d
-    double* red = mom + nout;                   // 256
-    const float* xb = x + (size_t)blockIdx.x * n * d;
-    const float* yb = y + (size_t)blockIdx.x * n * d;
-    {   // pass 1: column means
-        const int c = threadIdx.x % (2 * d), sub = threadIdx.x / (2 * d), nsub = 256 / (2 * d);
-        double acc = 0.0;
-        if (sub < nsub) {
-            const float* src = c < d ? xb + c : yb + (c - d);
-            for (int64_t r = sub; r < n; r += nsub) acc += (double)src[r * d];
-        }
-        red[threadIdx.x] = sub < nsub ? acc : 0.0;
-        __syncthreads();
-        if (threadIdx.x < 2 * d) {
-            double t = 0.0;
-            for (int s = 0; s < nsub; ++s) t += red[s * 2 * d + threadIdx.x];
-            mean[threadIdx.x] = t / (double)n;
-        }
-        __syncthreads();
+// Many small problems in ONE launch: problem b owns rows [b*n, (b+1)*n) of x and y (the per-step batch scores of a
+// training epoch, runners/ivae.py:86, wrappers.py:75: n = batch size).  ONE WAVE per problem, four problems per workgroup,
+// no LDS and no barrier: the same one-pass shifted moments as above with the shift taken from the problem's first (up to)
+// four rows -- exact zeros for a constant column, and n / 4 * 1e-16 bounds the relative error of the correction -- the
+// cross moments on v_mfma_f64_16x16x4_f64 straight from fragment-layout loads, sums and squares per lane and across the
+// four row lanes at the end, the correlation block written from the accumulators.  (Until round 3 a 256-thread workgroup
+// per problem staged float64 tiles in LDS in two passes: 290 us for 40 000 problems of 64 x 5 -- 0.35 TB/s of input.)
+template <int NT>
+__global__ __launch_bounds__(256) void k_corr_batched(const float* __restrict__ x, const float* __restrict__ y, int64_t n_blocks,
+                                                      int64_t n, int d, double* __restrict__ cc) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, q = lane >> 4;
+    const int64_t prob = (int64_t)blockIdx.x * 4 + w;
+    if (prob >= n_blocks) return;                            // (whole waves leave; nothing below synchronises)
+    const float* xb = x + (size_t)prob * n * d;
+    const float* yb = y + (size_t)prob * n * d;
+    auto all_q = [&](double v) {                             // the four row lanes of a column, in q order, in every lane
+        const double v0 = __shfl(v, c), v1 = __shfl(v, c + 16), v2 = __shfl(v, c + 32), v3 = __shfl(v, c + 48);
+        return ((v0 + v1) + v2) + v3;
+    };
+    const int S = n >= 4 ? 4 : (n >= 2 ? 2 : 1);             // a power of two: the division is exact
+    f64x4 acc[NT][NT];
+    double kx[NT], ky[NT], sxx[NT], syy[NT], sx[NT], sy[NT];
+    int col[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        col[t] = min(16 * t + c, d - 1);                     // (a clamped column computes on a duplicate; never written)
+        const double px = q < S ? (double)xb[(int64_t)q * d + col[t]] : 0.0;
+        const double py = q < S ? (double)yb[(int64_t)q * d + col[t]] : 0.0;
+        kx[t] = all_q(px) / (double)S;
+        ky[t] = all_q(py) / (double)S;
+        sxx[t] = 0.0; syy[t] = 0.0; sx[t] = 0.0; sy[t] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
     }
-    double acc[17];
+    constexpr int U = NT == 1 ? 8 : (NT == 2 ? 4 : 2);       // 4-row groups per batch of loads: 2 NT U loads in flight
+    const int64_t ngroups = (n + 3) / 4;
+    int64_t g0 = 0;
+    if ((uint64_t)n * (uint64_t)d * 4u < (1ull << 32)) {
+        // batches of complete groups: no address arithmetic (per-lane byte offsets fixed, the batch in the scalar offset of a
+        // buffer load over this problem's rows) and no masks -- the walk is bound by vector-instruction issue (see above)
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((uint64_t)n * d * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (int)((uint64_t)n * d * 4u), 0x00020000);
+        int vo[NT];
 #pragma unroll
-    for (int q = 0; q < 17; ++q) acc[q] = 0.0;
-    for (int64_t r0 = 0; r0 < n; r0 += CORR_ROWS) {
-        const int nr = (int)((n - r0) < CORR_ROWS ? (n - r0) : CORR_ROWS);
-        for (int idx = threadIdx.x; idx < CORR_ROWS * 2 * d; idx += 256) {
-            const int r = idx / (2 * d), c = idx - r * 2 * d;
-            double val = 0.0;
-            if (r < nr) val = (c < d ? (double)xb[(r0 + r) * d + c] : (double)yb[(r0 + r) * d + (c - d)]) - mean[c];
-            tile[r * ld + c] = val;
-        }
-        __syncthreads();
+        for (int t = 0; t < NT; ++t) vo[t] = (q * d + col[t]) * 4;
+        const int gbytes = 16 * d;                           // a 4-row group
+        const int nbatch = (int)((n / 4) / U);
+        for (int bi = 0; bi < nbatch; ++bi) {
+            const int so = bi * U * gbytes;
+            float xv[U][NT], yv[U][NT];
 #pragma unroll
-        for (int q = 0; q < 17; ++q) {
-            const int o = threadIdx.x + q * 256;
-            if (o < nout) {
-                int ca, cb;
-                if (o < d * d) { ca = o / d; cb = d + (o - ca * d); }
-                else { ca = cb = o - d * d; }
-                double s = 0.0;
-                for (int r = 0; r < nr; ++r) s += tile[r * ld + ca] * tile[r * ld + cb];
-                acc[q] += s;
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    xv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo[t], so + u * gbytes, 0));
+                    yv[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo[t], so + u * gbytes, 0));
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double a[NT], b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    a[t] = (double)xv[u][t] - kx[t];
+                    b[t] = (double)yv[u][t] - ky[t];
+                    sx[t] += a[t];
+                    sy[t] += b[t];
+                    sxx[t] += a[t] * a[t];
+                    syy[t] += b[t] * b[t];
+                }
+#pragma unroll
+                for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < NT; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
             }
         }
-        __syncthreads();
+        g0 = (int64_t)nbatch * U;
     }
+    for (; g0 < ngroups; g0 += U) {                          // what is left: partial batches, masked
+        float xv[U][NT], yv[U][NT];
 #pragma unroll
-    for (int q = 0; q < 17; ++q) {
-        const int o = threadIdx.x + q * 256;
-        if (o < nout) mom[o] = acc[q] / (double)(n - 1);
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = min((g0 + u) * 4 + q, n - 1);                  // (clamped: zeroed below)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { xv[u][t] = xb[row * d + col[t]]; yv[u][t] = yb[row * d + col[t]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool rok = (g0 + u) * 4 + q < n;
+            double a[NT], b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                a[t] = rok ? (double)xv[u][t] - kx[t] : 0.0;
+                b[t] = rok ? (double)yv[u][t] - ky[t] : 0.0;
+                sx[t] += a[t];
+                sy[t] += b[t];
+                sxx[t] += a[t] * a[t];
+                syy[t] += b[t] * b[t];
+            }
+#pragma unroll
+            for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < NT; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
     }
-    __syncthreads();
-    for (int o = threadIdx.x; o < d * d; o += 256) {
-        const int a = o / d, b = o - a * d;
-        double c = mom[o] / sqrt(mom[d * d + a]);
-        c = c / sqrt(mom[d * d + d + b]);
-        cc[(size_t)blockIdx.x * d * d + o] = clip_unit(c);
+    const double inv_n = 1.0 / (double)n, scale = 1.0 / (double)(n - 1);       // np.cov normalisation (cancels in the ratio)
+    double vx[NT], vy[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        sx[t] = all_q(sx[t]); sy[t] = all_q(sy[t]);
+        vx[t] = (all_q(sxx[t]) - sx[t] * sx[t] * inv_n) * scale;
+        vy[t] = (all_q(syy[t]) - sy[t] * sy[t] * inv_n) * scale;
     }
+    double* out = cc + (size_t)prob * d * d;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ia = 16 * ta + 4 * r + q;                                // this lane's output row; its x column lives in lane 4 r + q
+            const double sa = __shfl(sx[ta], 4 * r + q), va = __shfl(vx[ta], 4 * r + q);
+#pragma unroll
+            for (int tb = 0; tb < NT; ++tb) {
+                const int jb = 16 * tb + c;
+                double v = (acc[ta][tb][r] - sa * sy[tb] * inv_n) * scale / sqrt(va);
+                v = v / sqrt(vy[tb]);
+                if (ia < d && jb < d) out[ia * d + jb] = clip_unit(v);
+            }
+        }
 }
 
 hipError_t launch_corr_batched(const float* x, const float* y, int64_t n_blocks, int64_t n, int d, double* cc, hipStream_t st) {
-    static SmemCache cur = {};
-    const size_t smem = sizeof(double) * ((size_t)CORR_ROWS * (2 * d + 1) + 2 * d + (size_t)d * d + 2 * d + 256);
-    hipError_t e = set_smem((const void*)k_corr_batched, (int)smem, cur);      // d > ~40: above the default dynamic-LDS limit
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_corr_batched, dim3((unsigned)n_blocks), dim3(256), smem, st, x, y, n, d, cc);
+    const dim3 grid((unsigned)((n_blocks + 3) / 4)), block(256);
+    switch ((d + 15) / 16) {
+        case 1: hipLaunchKernelGGL(k_corr_batched<1>, grid, block, 0, st, x, y, n_blocks, n, d, cc); break;
+        case 2: hipLaunchKernelGGL(k_corr_batched<2>, grid, block, 0, st, x, y, n_blocks, n, d, cc); break;
+        case 3: hipLaunchKernelGGL(k_corr_batched<3>, grid, block, 0, st, x, y, n_blocks, n, d, cc); break;
+        case 4: hipLaunchKernelGGL(k_corr_batched<4>, grid, block, 0, st, x, y, n_blocks, n, d, cc); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

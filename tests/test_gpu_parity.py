@@ -299,8 +299,7 @@ def test_corr_kernel_matches_numpy_corrcoef(golden_dir):
 
 
 def test_corr_at_the_widest_supported_d():
-    """d = 64: four column tiles a side in ivae_corr; k_corr_batched needs 66 KB of dynamic LDS, above the default 64 KB
-    limit (per-device attribute)."""
+    """d = 64: four column tiles a side in ivae_corr and in ivae_corr_batched (16 accumulator tiles per wave)."""
     rng = np.random.RandomState(3)
     x = rng.randn(700, 64).astype(np.float32)
     y = (x @ rng.randn(64, 64).astype(np.float32) * 0.1 + rng.randn(700, 64)).astype(np.float32)
