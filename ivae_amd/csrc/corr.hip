@@ -23,6 +23,9 @@
 #define CORR_BLOCKS 256
 #define CORR_ROWS 64
 
+// The size the two-pass version needed (means, per-block sums, per-block centred moments).  The one-pass kernels use its
+// first CORR_BLOCKS * (d*d + 4d) doubles (2d less than this); the figure is kept: callers have sized buffers with it and the
+// built-in scratch of ivae_corr_static is declared from it.
 size_t corr_ws_bytes(int64_t n, int d) {
     (void)n;
     return sizeof(double) * ((size_t)2 * d + (size_t)CORR_BLOCKS * 2 * d + (size_t)CORR_BLOCKS * ((size_t)d * d + 2 * d));
