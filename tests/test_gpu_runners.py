@@ -82,6 +82,9 @@ def test_wrapper_checkpoints_inside_one_epoch_and_tiny_datasets(tmp_path, hidden
         assert int(ck['optimizer_state_dict']['state'][0]['step']) == ck['iteration']
     z, _, _, lg = runners.IVAE_wrapper(X[:40], U[:40], S[:40], batch_size=64, max_iter=3, seed=3, hidden_dim=hidden, lr=1e-2)
     assert z.shape == (40, 10) and len(lg.log_dict['elbo']) == 3 and all(np.isfinite(lg.log_dict['elbo']))
+    # no ground truth (S=None, wrappers.py:72-76 skips the score): losses are logged, every epoch's perf entry is the empty mean
+    z, _, _, lg = runners.IVAE_wrapper(X, U, None, batch_size=64, max_iter=45, seed=3, hidden_dim=hidden, lr=1e-2)
+    assert z.shape == (2600, 10) and len(lg.log_dict['elbo']) == 2 and lg.log_dict['perf'] == [0., 0.]
 
 
 def test_wrappers_generic_path_matches_fused_path_statistically():
