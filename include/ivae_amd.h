@@ -239,6 +239,12 @@ const char* ivae_version(void);
 /* Test hook, no counterpart in the reference: bit 0 makes ivae_train_steps's kernel skip one hand-off between the waves
  * of a model, so that the time-out report above can be exercised (tests/test_gpu_fused.py).  0 = normal operation. */
 int ivae_debug_fault_inject(int32_t mask);
+/* Measurement hook, no counterpart in the reference: the NEXT ivae_train_steps call of the calling thread records
+ * `start_event` on its stream directly before its first kernel launch and `stop_event` directly after its last
+ * (hipEvent_t handles created with timing; either may be NULL), so that the pair brackets the kernels and not the
+ * host work of the call around them (argument checks, step tables: ~20 us that events recorded by the caller include;
+ * bench.py's roofline figure).  The pair is used once. */
+int ivae_debug_launch_events(void* start_event, void* stop_event);
 
 #ifdef __cplusplus
 }

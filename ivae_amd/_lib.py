@@ -37,7 +37,7 @@ class IvaeWsLayout(C.Structure):
 
 EXPORTS = ["ivae_param_count", "ivae_workspace_bytes", "ivae_workspace_layout", "ivae_elbo_fwd_bwd", "ivae_forward",
            "ivae_pairwise", "ivae_pairwise_workspace_bytes", "ivae_backward", "ivae_adam_step", "ivae_elbo_adam_steps", "ivae_train_steps", "ivae_train_steps_supported", "ivae_corr_workspace_bytes", "ivae_corr", "ivae_corr_static", "ivae_corr_batched",
-           "ivae_last_hip_error", "ivae_version", "ivae_debug_fault_inject"]
+           "ivae_last_hip_error", "ivae_version", "ivae_debug_fault_inject", "ivae_debug_launch_events"]
 
 _lib = None
 
@@ -67,6 +67,7 @@ def lib():
     L.ivae_train_steps.argtypes = [pd, pc, vp, vp, vp, vp, vp, C.c_int64, vp, C.c_int64, vp, C.c_uint64, C.c_int32, C.c_int64,
                                    f64, C.POINTER(C.c_double), f64, f64, f64, vp, vp, vp, vp]
     L.ivae_debug_fault_inject.argtypes = [C.c_int32]
+    L.ivae_debug_launch_events.argtypes = [vp, vp]
     L.ivae_corr_workspace_bytes.argtypes = [C.c_int64, C.c_int32, C.POINTER(C.c_size_t)]
     L.ivae_corr.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp, C.c_size_t, vp]
     L.ivae_corr_static.argtypes = [vp, vp, C.c_int64, C.c_int32, vp, vp]

@@ -211,6 +211,15 @@ int ivae_debug_fault_inject(int32_t mask) {
     return IVAE_OK;
 }
 
+// ivae_debug_launch_events: events for the NEXT ivae_train_steps call of this thread (then forgotten)
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+int ivae_debug_launch_events(void* start_event, void* stop_event) {
+    g_ev_start = (hipEvent_t)start_event;
+    g_ev_stop = (hipEvent_t)stop_event;
+    return IVAE_OK;
+}
+
 int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, float* exp_avg, float* exp_avg_sq,
                      const float* x_data, const float* u_data, int64_t n_data, const int32_t* batch_idx,
                      int64_t batch_idx_stride, const float* eps, uint64_t seed, int32_t n_steps, int64_t step0, double lr,
@@ -238,6 +247,8 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, 
     A.w1 = (float)(1.0 - beta1); A.beta2 = (float)beta2; A.w2 = (float)(1.0 - beta2); A.adam_eps = (float)adam_eps;
     A.n_steps_total = n_steps;
     A.fault = g_fault;
+    hipEvent_t ev_start = g_ev_start, ev_stop = g_ev_stop;       // the call's first launch starts the clock, its last one stops it
+    g_ev_start = g_ev_stop = nullptr;
     for (int begin = 0; begin < n_steps; begin += FT_MAX_STEPS) {
         const int n = n_steps - begin < FT_MAX_STEPS ? n_steps - begin : FT_MAX_STEPS;
         A.n_steps = n; A.step_begin = begin; A.step0 = step0 + begin;
@@ -263,8 +274,10 @@ int ivae_train_steps(const IvaeDims* dims, const IvaeCoef* coef, float* params, 
             A.model0 = m0;
             for (int i = 0; i < nm; ++i) A.lr_scale[i] = model_lr ? (float)(model_lr[m0 + i] / lr) : 1.f;
             for (int i = nm; i < FT_MAX_MODELS; ++i) A.lr_scale[i] = 1.f;
+            const bool last = begin + n == n_steps && m0 + nm == dims->n_models;
             hipError_t e = launch_train_steps(dims->data_dim, dims->latent_dim, dims->aux_dim, dims->hidden_dim, A, nm,
-                                              (hipStream_t)stream);
+                                              (hipStream_t)stream, ev_start, last ? ev_stop : nullptr);
+            ev_start = nullptr;
             if (e != hipSuccess) return hip_fail(e, "ivae_train_steps");
         }
     }

@@ -34,4 +34,6 @@ struct FusedArgs {
 };
 
 bool fused_supported(int dd, int dl, int m, int h, int n_layers, int act, int batch);
-hipError_t launch_train_steps(int dd, int dl, int m, int h, const FusedArgs& A, int n_models, hipStream_t st);
+// ev_start / ev_stop (either may be null): events recorded on `st` directly before / after the launch
+hipError_t launch_train_steps(int dd, int dl, int m, int h, const FusedArgs& A, int n_models, hipStream_t st,
+                              hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);

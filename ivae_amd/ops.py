@@ -315,7 +315,7 @@ def train_steps_supported(shape, batch):
 
 
 def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_idx, step0, lr, eps=None, seed=0,
-                beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False, want_z_steps=False, table_steps=None):
+                beta1=0.9, beta2=0.999, adam_eps=1e-8, want_z=False, want_z_steps=False, table_steps=None, events=None):
     """ivae_train_steps: n_steps fused (elbo -> backward -> Adam) iterations for all packed models.
     params/exp_avg/exp_avg_sq (n_models, P) are updated in place; batch_idx (n_models, n_steps, B) int32.
     `lr`: one learning rate, or a sequence of n_models of them (packed runs with their own schedulers).
@@ -323,7 +323,9 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
     (n_models, n_steps, B, latent) z of every step instead.
     table_steps=(first, n): batch_idx is instead an epoch's whole (n_models, rows) int32 permutation table and the call runs
     the n steps whose rows start at column first * 64 of every model's row (no slice is cut: the library takes the
-    table's row stride)."""
+    table's row stride).
+    events=(start, stop): torch.cuda.Event pair recorded inside the library directly before the call's first kernel launch and
+    after its last (a measurement hook: bench.py)."""
     for t, n in ((params, "params"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (x_data, "x_data")):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
             raise RuntimeError(f"{n} must be a contiguous float32 ROCm tensor")
@@ -364,6 +366,11 @@ def train_steps(shape, coef, params, exp_avg, exp_avg_sq, x_data, u_data, batch_
         z = torch.empty(n_models, B, shape.latent_dim, dtype=torch.float32, device=dev) if want_z else None
         zs = (torch.empty(n_models, n_steps, B, shape.latent_dim, dtype=torch.float32, device=dev)
               if want_z_steps else None)
+        if events is not None:
+            # torch.cuda.Event pair (created with timing and recorded once, so that their handles exist): they are
+            # recorded inside the library, directly around the launches (include/ivae_amd.h: ivae_debug_launch_events)
+            check(_lib.lib().ivae_debug_launch_events(C.c_void_p(events[0].cuda_event), C.c_void_p(events[1].cuda_event)),
+                  "ivae_debug_launch_events")
         check(_lib.lib().ivae_train_steps(C.byref(dims), C.byref(coef), _ptr(params), _ptr(exp_avg), _ptr(exp_avg_sq),
                                           _ptr(x_data), _ptr(u_data), x_data.shape[1],
                                           C.c_void_p(batch_idx.data_ptr() + idx_off), idx_stride, _ptr(eps),

@@ -214,7 +214,11 @@ class FusedPackedTrainer:
 
     def _event(self):
         pool = getattr(self, "_ev_pool", None)
-        return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+        if pool:
+            return pool.pop()
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()                       # (an event's handle exists from its first record on)
+        return e
 
     def run(self, n_steps, timed=False, want_z=False):
         """Advance all models by n_steps; returns the (n_models, n_steps) loss tensor (device)."""
@@ -223,15 +227,15 @@ class FusedPackedTrainer:
             if self._perm is None or self._cursor >= self._nb:
                 self._reshuffle()
             k = min(n_steps, self.CHUNK, self._nb - self._cursor)
-            if timed:
-                e0, e1 = self._event(), self._event()
-                e0.record()
+            ev = None
+            if timed:       # the events are recorded inside the library, directly around the launch: recorded from here,
+                # around the call, they would also hold the host's ~20 us between the record and the launch
+                ev = (self._event(), self._event())
             loss, z = ops.train_steps(self.shape, self.coef, self.params, self.exp_avg, self.exp_avg_sq, self.x, self.u,
                                       self._perm, self.t, self.lr, seed=self.seed, want_z=want_z and k == n_steps,
-                                      table_steps=(self._cursor, k))
+                                      table_steps=(self._cursor, k), events=ev)
             if timed:
-                e1.record()
-                self._ev.append((e0, e1))
+                self._ev.append(ev)
                 self._launch_steps.append(k)
             out.append(loss)
             self.t += k
