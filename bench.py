@@ -419,6 +419,9 @@ def main():
                          "traffic": measured_traffic(tr.dominant_kernel, M, steps_per_launch) if fused else None,
                          "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, profiles/hbm_traffic.json)",
                          "avg_launch_us": round(kern_s * 1e6, 2),
+                         "timing": ("HIP events on the launch stream, recorded inside the library directly before and after the "
+                                    "kernel launch (ivae_debug_launch_events)" if fused else
+                                    "HIP events on the launch stream around each step's launches"),
                          "steps_per_launch": steps_per_launch, "algorithmic_flops_per_launch": algo_flops},
         }
         if fused:
